@@ -1,0 +1,113 @@
+/*
+ * minddet_hip.h -- C ABI of libminddet_hip.so (hand-written HIP for gfx950 / MI355X).
+ *
+ * Every entry point uses the MindSpore "AOT custom operator" convention that the reference
+ * uses for its own native ops, so the library is a drop-in behind ops.Custom(func_type="aot"):
+ *
+ *   reference CPU op : extern "C" int boxes_iou_nms_cpu(int nparam, void **params, int *ndims,
+ *                      int **shapes, const char **dtypes, void *stream, void *extra)
+ *                      minddet/models/centerpoint/det3d_ms/ops/iou-bev-nms-org.cpp:237
+ *   reference GPU ops: extern "C" int NmsGpu(int nparam, void** params, int* ndims,
+ *                      int64_t** shapes, const char** dtypes, void* stream, void* extra)
+ *                      minddet/models/centerpoint/det3d_ms/ops/test_custom_pytorch/
+ *                      iou3d_nms_kernel.cu:445,467,491,548
+ *
+ * Conventions (all ops):
+ *   - params[] = inputs, then outputs, in the order documented per op; an OPTIONAL trailing
+ *     workspace buffer (dtype "uint8") may follow the outputs -- when absent the op takes
+ *     stream-ordered scratch (hipMallocAsync/hipFreeAsync on `stream`).
+ *   - every pointer in params[] is DEVICE memory owned by the caller; outputs are fixed
+ *     shape and padded (keep[N] has `num` valid leading entries, the rest 0 --
+ *     iou-bev-nms-org.cpp:247-249,274-281).
+ *   - ndims[i] / shapes[i][j] describe params[i]; dtypes[i] is one of "uint8","int8","int16",
+ *     "int32","int64","float16","bfloat16","float32","float64" (ms_ext.cpp:6-7 + bfloat16).
+ *   - stream is a hipStream_t (may be NULL = default stream).  Work is ENQUEUED on it; the
+ *     ops never synchronise the device (the reference's cudaStreamSynchronize +
+ *     cudaMemcpy round trip, iou3d_nms_kernel.cu:448-449,515-517, is what this removes).
+ *   - `extra`: NULL, or a pointer to the op's attribute struct declared below (host memory,
+ *     read during the call only).
+ *   - return 0 on success; non-zero on failure (iou-bev-nms-org.cpp:238,282): 1 = wrong
+ *     nparam, 2 = bad dtype/shape, 3 = HIP runtime error, 4 = unsupported size.  No
+ *     exceptions, no stdout, no exit().
+ *   - re-entrant, no global mutable state; safe to call from several host threads on
+ *     different streams.
+ */
+#ifndef MINDDET_HIP_H_
+#define MINDDET_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MD_AOT_ARGS                                                                           \
+    int nparam, void **params, int *ndims, int64_t **shapes, const char **dtypes, void *stream, \
+        void *extra
+
+#define MD_OK 0
+#define MD_ERR_NPARAM 1
+#define MD_ERR_ARG 2
+#define MD_ERR_HIP 3
+#define MD_ERR_SIZE 4
+
+/* library / build info: returns a static string "minddet_hip <ver> gfx950". */
+const char *md_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Rotated (BEV) IoU + NMS -- same symbol names and parameter lists as the reference's AOT GPU
+ * ops (test_custom_pytorch/iou_gpu.py:14-81), so `"./iou_nms.so:NmsGpu"` can simply be
+ * re-pointed at this library.
+ * ------------------------------------------------------------------------------------------ */
+/* in: boxes_a[M,7] f32, boxes_b[N,7] f32 ; out: iou[M,N] f32.  iou3d_nms_kernel.cu:251-265 */
+int BoxesIouBevGpu(MD_AOT_ARGS);
+/* in: boxes_a[M,7] f32, boxes_b[N,7] f32 ; out: overlap[M,N] f32.  iou3d_nms_kernel.cu:236-249 */
+int BoxesOverlapBevGpu(MD_AOT_ARGS);
+/* in: boxes[N,7] f32 (sorted by score, descending), thresh[1] f32 ;
+ * out: keep[N] i64 (leading num valid, rest 0), num[1] i32.  Suppress iff IoU > thresh,
+ * IoU = overlap / fmaxf(sa+sb-overlap, 1e-8).  iou3d_nms_kernel.cu:267-311 + :491-546 */
+int NmsGpu(MD_AOT_ARGS);
+/* same I/O; axis-aligned IoU of the (x,y,dx,dy) footprint.  iou3d_nms_kernel.cu:314-372,548-601 */
+int NmsNormalGpu(MD_AOT_ARGS);
+/* Device twin of the reference's CPU operator boxes_iou_nms_cpu (iou-bev-nms-org.cpp:237-283,
+ * Python side nms_cpu.py:10-27): in: boxes[N,7] f32, thresh[1] f32 ; out: keep[N] i32,
+ * num[1] i32.  Suppress iff ovr >= thresh with ovr = overlap/(sa+sb-overlap) (no eps);
+ * zero-area boxes are dropped up front.  N comes from shapes[0][0] (the reference hard-codes
+ * 1000, :244). */
+int boxes_iou_nms_gpu(MD_AOT_ARGS);
+
+/* ------------------------------------------------------------------------------------------
+ * Axis-aligned IoU / NMS family
+ * ------------------------------------------------------------------------------------------ */
+typedef struct md_iou_attrs {
+    float eps; /* added to every width/height; pointpillars/src/core/box_np_ops.py:639 */
+} md_iou_attrs;
+/* iou_jit: in boxes[N,4] f32, query[K,4] f32 ; out overlaps[N,K] f32.  extra: md_iou_attrs
+ * (NULL -> eps 0).  pointpillars/src/core/box_np_ops.py:639-679 */
+int md_iou_aligned(MD_AOT_ARGS);
+
+typedef struct md_nms_attrs {
+    float iou_threshold;
+    float eps;         /* mode 0 only */
+    int32_t mode;      /* 0 nms_jit (>= thr, eps)       pointpillars/src/core/nms.py:85-112
+                          1 apply_nms (+1 px, > thr)     pointpillars/src/core/nms.py:7-41
+                          2 strict > thr, fmaxf(union,1e-8) (iou_normal on corner boxes) */
+    int32_t max_output; /* <=0: no cap; else keep only the first max_output survivors */
+} md_nms_attrs;
+/* Greedy NMS over B independent lists of corner boxes already sorted by descending score.
+ * in : boxes[B,N,4] f32 (or [N,4]), count[B] i32 (valid leading boxes per list; may be a
+ *      NULL pointer = all N), group[B,N] i32 (class / task key: boxes with different keys
+ *      never suppress each other; may be a NULL pointer)
+ * out: keep_mask[B,N] u8, keep_idx[B,N] i32 (leading num valid, rest 0), num[B] i32
+ * extra: md_nms_attrs (required). */
+int md_nms_aligned(MD_AOT_ARGS);
+
+/* circle_nms (centerpoint/det3d_ms/core/utils/circle_nms_jit.py:6-36):
+ * in xy[N,2] f32 sorted by score desc, thresh[1] f32 ; out keep_mask[N] u8, keep_idx[N] i32,
+ * num[1] i32.  Suppress iff squared centre distance <= thresh. */
+int md_circle_nms(MD_AOT_ARGS);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINDDET_HIP_H_ */

@@ -1,0 +1,513 @@
+// nms.hip -- NMS family + IoU matrices for gfx950 (MI355X), behind the AOT C ABI.
+//
+// Reference semantics (minddet/models/...):
+//   NmsGpu / NmsNormalGpu     centerpoint/det3d_ms/ops/test_custom_pytorch/iou3d_nms_kernel.cu:491-601
+//                             (kernels centerpoint/det3d_ms/ops/iou3d_nms/src/iou3d_nms_kernel.cu:267-372,
+//                              host bitmask reduction iou3d_nms.cpp:102-133)
+//   boxes_iou_nms_gpu         centerpoint/det3d_ms/ops/iou-bev-nms-org.cpp:237-283
+//   BoxesIouBevGpu/OverlapBev iou3d_nms_kernel.cu:236-265
+//   md_iou_aligned            pointpillars/src/core/box_np_ops.py:639-679
+//   md_nms_aligned            pointpillars/src/core/nms.py:7-41,85-112
+//   md_circle_nms             centerpoint/det3d_ms/core/utils/circle_nms_jit.py:6-36
+//
+// MI355X design (not a translation of the CUDA file):
+//   * 64x64 suppression tiles are owned by a 256-thread workgroup = 4 wave64; lane = COLUMN
+//     box (held in registers), the row box is an LDS broadcast, and the 64-bit mask word of a
+//     (row, column-block) is ONE __ballot over the wave -- no per-lane bit loop, no shifts.
+//     Only the upper-triangular tiles are launched.
+//   * the greedy pass that the reference runs on the HOST after a blocking D2H copy of the
+//     whole mask runs ON DEVICE in one workgroup: wave 0 resolves a 64-box diagonal block
+//     with scalar bit tricks (one iteration per KEPT box, not per box), then the four waves
+//     OR-reduce the kept rows' words into the "removed" words of later column blocks with
+//     cross-lane DPP reductions.  No sync, no copies: the op is stream-ordered.
+//   * batched (image, class)-keyed NMS: grid.y = list index, optional int32 group key.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "aot.h"
+#include "rot_geom.h"
+
+#pragma clang fp contract(off)
+
+namespace md {
+
+constexpr int TILE = 64;
+
+__global__ void rot_prep_kernel(const float *__restrict__ boxes, int n, float *__restrict__ rec) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r[ROT_REC];
+    float b[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) b[k] = boxes[(size_t)i * 7 + k];
+    rot_make_record(b, r);
+#pragma unroll
+    for (int k = 0; k < ROT_REC; ++k) rec[(size_t)i * ROT_REC + k] = r[k];
+}
+
+// linear upper-triangular tile id -> (row block, col block)
+__device__ __forceinline__ void tri_tile(int t, int cb, int &rb, int &cbk) {
+    int r = 0;
+    while (t >= cb - r) { t -= cb - r; ++r; }
+    rb = r;
+    cbk = r + t;
+}
+
+// MODE 0: IoU = so / fmaxf(sa+sb-so, 1e-8), suppress iff >  thr   (NmsGpu)
+// MODE 1: ovr = so / (sa+sb-so),            suppress iff >= thr   (boxes_iou_nms_cpu)
+template <int MODE>
+__global__ __launch_bounds__(256) void nms_rot_mask_kernel(const float *__restrict__ rec, int n,
+                                                            const float *__restrict__ thr_p,
+                                                            unsigned long long *__restrict__ mask, int cb) {
+    __shared__ float row_rec[TILE * ROT_REC];
+    __shared__ float poly[3 * ROT_PTS * 256];
+    int rb, cbk;
+    tri_tile(blockIdx.x, cb, rb, cbk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < TILE * ROT_REC; e += 256) {
+        const int g = rb * TILE + e / ROT_REC;
+        row_rec[e] = g < n ? rec[(size_t)g * ROT_REC + e % ROT_REC] : 0.f;
+    }
+    const int gc = cbk * TILE + lane;
+    float col[ROT_REC];
+#pragma unroll
+    for (int k = 0; k < ROT_REC; ++k) col[k] = gc < n ? rec[(size_t)gc * ROT_REC + k] : 0.f;
+    const float thr = *thr_p;
+    __syncthreads();
+    float *scratch = poly + tid;
+    for (int rr = wave * 16; rr < wave * 16 + 16; ++rr) {
+        const int gr = rb * TILE + rr;
+        if (gr >= n) break;  // wave-uniform
+        bool pred = false;
+        if (gc < n && (cbk != rb || lane > rr)) {
+            const float *A = row_rec + rr * ROT_REC;
+            const float so = rot_overlap(A, col, scratch, 256);
+            if (MODE == 0) {
+                const float v = so / fmaxf(A[14] + col[14] - so, ROT_EPS);
+                pred = v > thr;
+            } else {
+                const float v = so / (A[14] + col[14] - so);
+                pred = v >= thr;
+            }
+        }
+        const unsigned long long w = __ballot(pred);
+        if (lane == 0) mask[(size_t)gr * cb + cbk] = w;
+    }
+}
+
+// ------------------------------------------------------------------ axis-aligned variants
+// footprint of a 7-float box, iou_normal (iou3d_nms_kernel.cu:314-325)
+__device__ __forceinline__ float iou_normal7(const float *a, const float *b) {
+    const float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+    const float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+    const float w = fmaxf(right - left, 0.f), h = fmaxf(bottom - top, 0.f);
+    const float inter = w * h;
+    const float sa = a[3] * a[4], sb = b[3] * b[4];
+    return inter / fmaxf(sa + sb - inter, ROT_EPS);
+}
+
+__global__ __launch_bounds__(256) void nms_normal7_mask_kernel(const float *__restrict__ boxes, int n,
+                                                                const float *__restrict__ thr_p,
+                                                                unsigned long long *__restrict__ mask, int cb) {
+    __shared__ float row_box[TILE * 8];
+    int rb, cbk;
+    tri_tile(blockIdx.x, cb, rb, cbk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < TILE * 7; e += 256) {
+        const int g = rb * TILE + e / 7;
+        row_box[(e / 7) * 8 + e % 7] = g < n ? boxes[(size_t)g * 7 + e % 7] : 0.f;
+    }
+    const int gc = cbk * TILE + lane;
+    float col[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) col[k] = gc < n ? boxes[(size_t)gc * 7 + k] : 0.f;
+    const float thr = *thr_p;
+    __syncthreads();
+    for (int rr = wave * 16; rr < wave * 16 + 16; ++rr) {
+        const int gr = rb * TILE + rr;
+        if (gr >= n) break;
+        bool pred = false;
+        if (gc < n && (cbk != rb || lane > rr)) pred = iou_normal7(row_box + rr * 8, col) > thr;
+        const unsigned long long w = __ballot(pred);
+        if (lane == 0) mask[(size_t)gr * cb + cbk] = w;
+    }
+}
+
+// corner boxes [x1,y1,x2,y2]; modes documented in minddet_hip.h (md_nms_attrs)
+__global__ __launch_bounds__(256) void nms_aligned_mask_kernel(const float *__restrict__ boxes_all,
+                                                                const int *__restrict__ count,
+                                                                const int *__restrict__ group_all, int n_max,
+                                                                float thr, float eps, int mode,
+                                                                unsigned long long *__restrict__ mask_all, int cb) {
+    __shared__ float row_box[TILE * 4];
+    __shared__ int row_grp[TILE];
+    const int list = blockIdx.y;
+    const int n = count ? min(count[list], n_max) : n_max;
+    int rb, cbk;
+    tri_tile(blockIdx.x, cb, rb, cbk);
+    if (rb * TILE >= n) return;  // block-uniform: nothing valid in this row block
+    const float *boxes = boxes_all + (size_t)list * n_max * 4;
+    const int *group = group_all ? group_all + (size_t)list * n_max : nullptr;
+    unsigned long long *mask = mask_all + (size_t)list * n_max * cb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < TILE) {
+        const int g = rb * TILE + tid;
+        float4 v = g < n ? *reinterpret_cast<const float4 *>(boxes + (size_t)g * 4) : make_float4(0, 0, 0, 0);
+        row_box[tid * 4 + 0] = v.x; row_box[tid * 4 + 1] = v.y; row_box[tid * 4 + 2] = v.z; row_box[tid * 4 + 3] = v.w;
+        row_grp[tid] = (group && g < n) ? group[g] : 0;
+    }
+    const int gc = cbk * TILE + lane;
+    const float4 c = gc < n ? *reinterpret_cast<const float4 *>(boxes + (size_t)gc * 4) : make_float4(0, 0, 0, 0);
+    const int cg = (group && gc < n) ? group[gc] : 0;
+    const float off = mode == 1 ? 1.0f : eps;
+    const float area_c = (c.z - c.x + off) * (c.w - c.y + off);
+    __syncthreads();
+    for (int rr = wave * 16; rr < wave * 16 + 16; ++rr) {
+        const int gr = rb * TILE + rr;
+        if (gr >= n) break;
+        bool pred = false;
+        if (gc < n && (cbk != rb || lane > rr) && row_grp[rr] == cg) {
+            const float ax1 = row_box[rr * 4], ay1 = row_box[rr * 4 + 1], ax2 = row_box[rr * 4 + 2], ay2 = row_box[rr * 4 + 3];
+            const float area_a = (ax2 - ax1 + off) * (ay2 - ay1 + off);
+            const float w = rhi(rlo(ax2, c.z) - rhi(ax1, c.x) + off, 0.0f);
+            const float h = rhi(rlo(ay2, c.w) - rhi(ay1, c.y) + off, 0.0f);
+            const float inter = w * h;
+            float ovr;
+            if (mode == 2) ovr = inter / fmaxf(area_a + area_c - inter, ROT_EPS);
+            else ovr = inter / (area_a + area_c - inter);
+            pred = mode == 0 ? (ovr >= thr) : (ovr > thr);
+        }
+        const unsigned long long w64 = __ballot(pred);
+        if (lane == 0) mask[(size_t)gr * cb + cbk] = w64;
+    }
+}
+
+__global__ __launch_bounds__(256) void circle_mask_kernel(const float *__restrict__ xy, int n,
+                                                           const float *__restrict__ thr_p,
+                                                           unsigned long long *__restrict__ mask, int cb) {
+    __shared__ float row_xy[TILE * 2];
+    int rb, cbk;
+    tri_tile(blockIdx.x, cb, rb, cbk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < TILE * 2) {
+        const int g = rb * TILE + tid / 2;
+        row_xy[tid] = g < n ? xy[(size_t)g * 2 + (tid & 1)] : 0.f;
+    }
+    const int gc = cbk * TILE + lane;
+    const float cx = gc < n ? xy[(size_t)gc * 2] : 0.f, cy = gc < n ? xy[(size_t)gc * 2 + 1] : 0.f;
+    const float thr = *thr_p;
+    __syncthreads();
+    for (int rr = wave * 16; rr < wave * 16 + 16; ++rr) {
+        const int gr = rb * TILE + rr;
+        if (gr >= n) break;
+        bool pred = false;
+        if (gc < n && (cbk != rb || lane > rr)) {
+            const float dx = row_xy[rr * 2] - cx, dy = row_xy[rr * 2 + 1] - cy;
+            pred = (dx * dx + dy * dy) <= thr;
+        }
+        const unsigned long long w = __ballot(pred);
+        if (lane == 0) mask[(size_t)gr * cb + cbk] = w;
+    }
+}
+
+// ------------------------------------------------------------------ on-device greedy pass
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v);
+    const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One workgroup per list.  mask rows are valid for column blocks >= the row's block.
+// dead_area: optional per-box area array (stride in floats) -- boxes with area == 0 are
+// removed up front without suppressing anything (iou-bev-nms-org.cpp:250-256).
+template <typename KeepT>
+__global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long *__restrict__ mask_all,
+                                                        const int *__restrict__ count, int n_max, int cb,
+                                                        const float *__restrict__ dead_area, int dead_stride,
+                                                        int max_output, KeepT *__restrict__ keep_all,
+                                                        int *__restrict__ num_all,
+                                                        unsigned char *__restrict__ keepmask_all) {
+    extern __shared__ unsigned long long remv[];  // cb words + 1 (kept word broadcast)
+    const int list = blockIdx.x;
+    const int n = count ? min(count[list], n_max) : n_max;
+    const unsigned long long *mask = mask_all + (size_t)list * n_max * cb;
+    KeepT *keep = keep_all + (size_t)list * n_max;
+    unsigned char *keepmask = keepmask_all ? keepmask_all + (size_t)list * n_max : nullptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int j = tid; j < cb + 1; j += 256) remv[j] = 0ull;
+    for (int i = tid; i < n_max; i += 256) {
+        keep[i] = 0;
+        if (keepmask) keepmask[i] = 0;
+    }
+    __syncthreads();
+    const int nb = (n + TILE - 1) / TILE;
+    int total = 0;  // kept so far (uniform)
+    for (int blk = 0; blk < nb; ++blk) {
+        const int base = blk * TILE;
+        if (wave == 0) {
+            const int r = base + lane;
+            unsigned long long diag = 0ull;
+            bool dead = r >= n;
+            if (r < n) {
+                diag = mask[(size_t)r * cb + blk];
+                if (dead_area && dead_area[(size_t)r * dead_stride] == 0.f) dead = true;
+            }
+            unsigned long long cur = uniform64(remv[blk]) | __ballot(dead);
+            if (max_output > 0 && total >= max_output) cur = ~0ull;
+            unsigned long long kept = 0ull;
+            unsigned long long cand = ~cur;
+            int quota = max_output > 0 ? max_output - total : 64;
+            while (cand != 0ull && quota > 0) {
+                const int i = __ffsll((long long)cand) - 1;
+                kept |= 1ull << i;
+                --quota;
+                const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)diag, i);
+                const unsigned int hi = __builtin_amdgcn_readlane((unsigned int)(diag >> 32), i);
+                cur |= ((unsigned long long)hi << 32) | lo | (1ull << i);
+                cand = ~cur;
+            }
+            if ((kept >> lane) & 1ull) {
+                const int pos = total + __popcll(kept & ((1ull << lane) - 1ull));
+                keep[pos] = (KeepT)r;
+                if (keepmask) keepmask[r] = 1;
+            }
+            if (lane == 0) remv[cb] = kept;
+        }
+        __syncthreads();
+        const unsigned long long kept = uniform64(remv[cb]);
+        total += __popcll(kept);
+        // OR the kept rows' words into the removed-words of later column blocks:
+        // lane = row of this block, one wave per column block, DPP/shuffle OR-reduction.
+        const bool mine = (kept >> lane) & 1ull;
+        for (int j = blk + 1 + wave; j < cb; j += 4) {
+            unsigned long long v = mine ? mask[(size_t)(base + lane) * cb + j] : 0ull;
+            v = wave_or64(v);
+            if (lane == 0) remv[j] |= v;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) num_all[list] = total;
+}
+
+// ------------------------------------------------------------------ IoU matrices
+template <int IOU>
+__global__ __launch_bounds__(256) void rot_pair_matrix_kernel(const float *__restrict__ rec_a, int na,
+                                                               const float *__restrict__ rec_b, int nb,
+                                                               float *__restrict__ out) {
+    __shared__ float poly[3 * ROT_PTS * 256];
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)na * nb;
+    if (idx >= total) return;
+    const int i = (int)(idx / nb), j = (int)(idx % nb);
+    float A[ROT_REC], B[ROT_REC];
+#pragma unroll
+    for (int k = 0; k < ROT_REC; ++k) {
+        A[k] = rec_a[(size_t)i * ROT_REC + k];
+        B[k] = rec_b[(size_t)j * ROT_REC + k];
+    }
+    const float so = rot_overlap(A, B, poly + threadIdx.x, 256);
+    out[idx] = IOU ? so / fmaxf(A[14] + B[14] - so, ROT_EPS) : so;
+}
+
+__global__ void iou_aligned_kernel(const float *__restrict__ boxes, int n, const float *__restrict__ query, int k,
+                                   float eps, float *__restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * k) return;
+    const int i = (int)(idx / k), q = (int)(idx % k);
+    const float4 b = *reinterpret_cast<const float4 *>(boxes + (size_t)i * 4);
+    const float4 c = *reinterpret_cast<const float4 *>(query + (size_t)q * 4);
+    const float qa = (c.z - c.x + eps) * (c.w - c.y + eps);
+    float v = 0.f;
+    const float iw = rlo(b.z, c.z) - rhi(b.x, c.x) + eps;
+    if (iw > 0) {
+        const float ih = rlo(b.w, c.w) - rhi(b.y, c.y) + eps;
+        if (ih > 0) {
+            const float ua = (b.z - b.x + eps) * (b.w - b.y + eps) + qa - iw * ih;
+            v = iw * ih / ua;
+        }
+    }
+    out[idx] = v;
+}
+
+static inline size_t scan_lds(int cb) { return (size_t)(cb + 1) * sizeof(unsigned long long); }
+
+}  // namespace md
+
+using namespace md;
+
+extern "C" const char *md_version(void) { return "minddet_hip 0.1 gfx950"; }
+
+static int check_boxes7(int nparam, int want, void **params, int *ndims, int64_t **shapes, const char **dtypes,
+                        int64_t &n) {
+    if (nparam != want && nparam != want + 1) return MD_ERR_NPARAM;
+    if (!params || !dtype_is(dtypes, 0, "float32")) return MD_ERR_ARG;
+    n = dim(ndims, shapes, 0, 0);
+    if (n < 0 || dim(ndims, shapes, 0, 1) != 7) return MD_ERR_ARG;
+    if (n > (1 << 16)) return MD_ERR_SIZE;
+    return MD_OK;
+}
+
+template <int MODE, typename KeepT>
+static int rot_nms_impl(MD_AOT_ARGS, const char *keep_dtype) {
+    int64_t n;
+    int rc = check_boxes7(nparam, 4, params, ndims, shapes, dtypes, n);
+    if (rc) return rc;
+    if (!dtype_is(dtypes, 1, "float32") || !dtype_is(dtypes, 2, keep_dtype) || !dtype_is(dtypes, 3, "int32"))
+        return MD_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    KeepT *keep = (KeepT *)params[2];
+    int *num = (int *)params[3];
+    if (n == 0) return hipMemsetAsync(num, 0, sizeof(int), s) == hipSuccess ? MD_OK : MD_ERR_HIP;
+    const int cb = (int)((n + TILE - 1) / TILE);
+    const size_t rec_bytes = align_up((size_t)n * ROT_REC * 4, 256);
+    const size_t mask_bytes = (size_t)n * cb * 8;
+    Scratch ws;
+    rc = ws.acquire(rec_bytes + mask_bytes, nparam, params, ndims, shapes, 4, s);
+    if (rc) return rc;
+    float *rec = (float *)ws.ptr;
+    unsigned long long *mask = (unsigned long long *)((char *)ws.ptr + rec_bytes);
+    hipLaunchKernelGGL(rot_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float *)params[0], (int)n, rec);
+    hipLaunchKernelGGL((nms_rot_mask_kernel<MODE>), dim3(cb * (cb + 1) / 2), dim3(256), 0, s, rec, (int)n,
+                       (const float *)params[1], mask, cb);
+    hipLaunchKernelGGL((nms_scan_kernel<KeepT>), dim3(1), dim3(256), scan_lds(cb), s, mask, (const int *)nullptr,
+                       (int)n, cb, MODE == 1 ? rec + 14 : (const float *)nullptr, ROT_REC, 0, keep, num,
+                       (unsigned char *)nullptr);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+
+extern "C" int NmsGpu(MD_AOT_ARGS) {
+    return rot_nms_impl<0, long long>(nparam, params, ndims, shapes, dtypes, stream, extra, "int64");
+}
+
+extern "C" int boxes_iou_nms_gpu(MD_AOT_ARGS) {
+    return rot_nms_impl<1, int>(nparam, params, ndims, shapes, dtypes, stream, extra, "int32");
+}
+
+extern "C" int NmsNormalGpu(MD_AOT_ARGS) {
+    int64_t n;
+    int rc = check_boxes7(nparam, 4, params, ndims, shapes, dtypes, n);
+    if (rc) return rc;
+    if (!dtype_is(dtypes, 1, "float32") || !dtype_is(dtypes, 2, "int64") || !dtype_is(dtypes, 3, "int32"))
+        return MD_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) return hipMemsetAsync(params[3], 0, sizeof(int), s) == hipSuccess ? MD_OK : MD_ERR_HIP;
+    const int cb = (int)((n + TILE - 1) / TILE);
+    Scratch ws;
+    rc = ws.acquire((size_t)n * cb * 8, nparam, params, ndims, shapes, 4, s);
+    if (rc) return rc;
+    unsigned long long *mask = (unsigned long long *)ws.ptr;
+    hipLaunchKernelGGL(nms_normal7_mask_kernel, dim3(cb * (cb + 1) / 2), dim3(256), 0, s, (const float *)params[0],
+                       (int)n, (const float *)params[1], mask, cb);
+    hipLaunchKernelGGL((nms_scan_kernel<long long>), dim3(1), dim3(256), scan_lds(cb), s, mask, (const int *)nullptr,
+                       (int)n, cb, (const float *)nullptr, 0, 0, (long long *)params[2], (int *)params[3],
+                       (unsigned char *)nullptr);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+
+template <int IOU>
+static int rot_matrix_impl(MD_AOT_ARGS) {
+    if (nparam != 3 && nparam != 4) return MD_ERR_NPARAM;
+    if (!params || !dtype_is(dtypes, 0, "float32") || !dtype_is(dtypes, 1, "float32") || !dtype_is(dtypes, 2, "float32"))
+        return MD_ERR_ARG;
+    const int64_t na = dim(ndims, shapes, 0, 0), nb = dim(ndims, shapes, 1, 0);
+    if (na < 0 || nb < 0 || dim(ndims, shapes, 0, 1) != 7 || dim(ndims, shapes, 1, 1) != 7) return MD_ERR_ARG;
+    if (na == 0 || nb == 0) return MD_OK;
+    if (na > (1 << 24) || nb > (1 << 24)) return MD_ERR_SIZE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t ra = align_up((size_t)na * ROT_REC * 4, 256), rbb = (size_t)nb * ROT_REC * 4;
+    Scratch ws;
+    int rc = ws.acquire(ra + rbb, nparam, params, ndims, shapes, 3, s);
+    if (rc) return rc;
+    float *rec_a = (float *)ws.ptr, *rec_b = (float *)((char *)ws.ptr + ra);
+    hipLaunchKernelGGL(rot_prep_kernel, dim3((na + 255) / 256), dim3(256), 0, s, (const float *)params[0], (int)na, rec_a);
+    hipLaunchKernelGGL(rot_prep_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, (const float *)params[1], (int)nb, rec_b);
+    const size_t total = (size_t)na * nb;
+    hipLaunchKernelGGL((rot_pair_matrix_kernel<IOU>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rec_a,
+                       (int)na, rec_b, (int)nb, (float *)params[2]);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+
+extern "C" int BoxesIouBevGpu(MD_AOT_ARGS) {
+    return rot_matrix_impl<1>(nparam, params, ndims, shapes, dtypes, stream, extra);
+}
+extern "C" int BoxesOverlapBevGpu(MD_AOT_ARGS) {
+    return rot_matrix_impl<0>(nparam, params, ndims, shapes, dtypes, stream, extra);
+}
+
+extern "C" int md_iou_aligned(MD_AOT_ARGS) {
+    if (nparam != 3) return MD_ERR_NPARAM;
+    if (!params || !dtype_is(dtypes, 0, "float32") || !dtype_is(dtypes, 1, "float32") || !dtype_is(dtypes, 2, "float32"))
+        return MD_ERR_ARG;
+    const int64_t n = dim(ndims, shapes, 0, 0), k = dim(ndims, shapes, 1, 0);
+    if (n < 0 || k < 0 || dim(ndims, shapes, 0, 1) != 4 || dim(ndims, shapes, 1, 1) != 4) return MD_ERR_ARG;
+    if (n == 0 || k == 0) return MD_OK;
+    const float eps = extra ? ((const md_iou_attrs *)extra)->eps : 0.f;
+    const size_t total = (size_t)n * k;
+    hipLaunchKernelGGL(iou_aligned_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)params[0], (int)n, (const float *)params[1], (int)k, eps, (float *)params[2]);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+
+extern "C" int md_nms_aligned(MD_AOT_ARGS) {
+    if (nparam != 6 && nparam != 7) return MD_ERR_NPARAM;
+    if (!params || !extra || !params[0]) return MD_ERR_ARG;
+    if (!dtype_is(dtypes, 0, "float32") || !dtype_is(dtypes, 1, "int32") || !dtype_is(dtypes, 2, "int32") ||
+        !dtype_is(dtypes, 3, "uint8") || !dtype_is(dtypes, 4, "int32") || !dtype_is(dtypes, 5, "int32"))
+        return MD_ERR_ARG;
+    const int nd = ndims ? ndims[0] : -1;
+    if (nd != 2 && nd != 3) return MD_ERR_ARG;
+    const int64_t B = nd == 3 ? shapes[0][0] : 1, n = shapes[0][nd - 2];
+    if (shapes[0][nd - 1] != 4 || B < 0 || n < 0) return MD_ERR_ARG;
+    if (n > (1 << 16) || B > 65535) return MD_ERR_SIZE;
+    const md_nms_attrs *at = (const md_nms_attrs *)extra;
+    if (at->mode < 0 || at->mode > 2) return MD_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) return MD_OK;
+    if (n == 0) return hipMemsetAsync(params[5], 0, sizeof(int) * B, s) == hipSuccess ? MD_OK : MD_ERR_HIP;
+    const int cb = (int)((n + TILE - 1) / TILE);
+    Scratch ws;
+    int rc = ws.acquire((size_t)B * n * cb * 8, nparam, params, ndims, shapes, 6, s);
+    if (rc) return rc;
+    unsigned long long *mask = (unsigned long long *)ws.ptr;
+    hipLaunchKernelGGL(nms_aligned_mask_kernel, dim3(cb * (cb + 1) / 2, (unsigned)B), dim3(256), 0, s,
+                       (const float *)params[0], (const int *)params[1], (const int *)params[2], (int)n,
+                       at->iou_threshold, at->eps, at->mode, mask, cb);
+    hipLaunchKernelGGL((nms_scan_kernel<int>), dim3((unsigned)B), dim3(256), scan_lds(cb), s, mask,
+                       (const int *)params[1], (int)n, cb, (const float *)nullptr, 0, at->max_output, (int *)params[4],
+                       (int *)params[5], (unsigned char *)params[3]);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+
+extern "C" int md_circle_nms(MD_AOT_ARGS) {
+    if (nparam != 5 && nparam != 6) return MD_ERR_NPARAM;
+    if (!params || !dtype_is(dtypes, 0, "float32") || !dtype_is(dtypes, 1, "float32") || !dtype_is(dtypes, 2, "uint8") ||
+        !dtype_is(dtypes, 3, "int32") || !dtype_is(dtypes, 4, "int32"))
+        return MD_ERR_ARG;
+    const int64_t n = dim(ndims, shapes, 0, 0);
+    if (n < 0 || dim(ndims, shapes, 0, 1) != 2) return MD_ERR_ARG;
+    if (n > (1 << 16)) return MD_ERR_SIZE;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) return hipMemsetAsync(params[4], 0, sizeof(int), s) == hipSuccess ? MD_OK : MD_ERR_HIP;
+    const int cb = (int)((n + TILE - 1) / TILE);
+    Scratch ws;
+    int rc = ws.acquire((size_t)n * cb * 8, nparam, params, ndims, shapes, 5, s);
+    if (rc) return rc;
+    unsigned long long *mask = (unsigned long long *)ws.ptr;
+    hipLaunchKernelGGL(circle_mask_kernel, dim3(cb * (cb + 1) / 2), dim3(256), 0, s, (const float *)params[0], (int)n,
+                       (const float *)params[1], mask, cb);
+    hipLaunchKernelGGL((nms_scan_kernel<int>), dim3(1), dim3(256), scan_lds(cb), s, mask, (const int *)nullptr, (int)n,
+                       cb, (const float *)nullptr, 0, 0, (int *)params[3], (int *)params[4], (unsigned char *)params[2]);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
