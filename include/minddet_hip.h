@@ -107,6 +107,26 @@ int md_nms_aligned(MD_AOT_ARGS);
  * num[1] i32.  Suppress iff squared centre distance <= thresh. */
 int md_circle_nms(MD_AOT_ARGS);
 
+/* ------------------------------------------------------------------------------------------
+ * Conv + folded BN + (residual) + ReLU, implicit GEMM on MFMA (bf16 in, fp32 accumulate)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct md_conv2d_attrs {
+    int32_t kh, kw, stride, pad; /* square stride / symmetric zero padding */
+    int32_t relu;                /* 1: ReLU after bias (+ residual) */
+} md_conv2d_attrs;
+/* Replaces Conv2d -> BatchNorm2d(eval) -> [+ residual] -> ReLU of the reference graphs
+ * (centernet/src/resnet.py:109-178,181-252; centerpoint/det3d_ms/models/necks/rpn.py:9-154).
+ * in : x[N,H,W,Cin] bf16 NHWC (Cin % 8 == 0),
+ *      w[Cout_pad, Kpad] bf16, K ordered (kh,kw,ci), BN folded (w' = w*gamma/sqrt(var+eps)),
+ *        Kpad = roundup(kh*kw*Cin, 64) zero padded, Cout_pad = roundup(Cout, md_conv2d_cout_tile(Cout)),
+ *      bias[Cout_pad] f32 (b' = beta - mean*gamma/sqrt(var+eps)),
+ *      residual[N,Ho,Wo,Cout] bf16 or a NULL pointer
+ * out: y[N,Ho,Wo,Cout] bf16 (Cout % 8 == 0).   extra: md_conv2d_attrs (required). */
+int md_conv2d(MD_AOT_ARGS);
+/* tile of output channels the dispatcher uses for a given Cout (32, 64 or 128): the packer
+ * pads Cout up to a multiple of it.  Pure function, callable without a GPU. */
+int md_conv2d_cout_tile(int cout);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,168 @@
+// pool.hip -- HBM-bound NHWC bf16 helpers between the conv kernels: max-pool, FPN top-down
+// (nearest upsample + lateral add), channel slice + cast.  All are pure streaming kernels:
+// 16 bytes (8 channels) per lane, one 128-B line per 8 lanes, grid-stride.
+//
+// Reference counterparts: zero-pad + MaxPool2d(3,2) of the ResNet stem
+// (minddet/models/centernet/src/resnet.py:199-204,247); the FPN top-down path and the channel
+// slice have no reference counterpart -- "parity unpinned", checked against
+// torch.nn.functional on the same bf16 values (max / add of two bf16 are exact or one rounding).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "aot.h"
+
+namespace md {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ float pbf2f(unsigned v16) { return __uint_as_float(v16 << 16); }
+__device__ __forceinline__ unsigned pf2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+// max of two packed bf16 pairs (compare as floats; -0/+0 and NaN corner cases follow fmaxf)
+__device__ __forceinline__ unsigned max_bf16x2(unsigned a, unsigned b) {
+    const float alo = pbf2f(a & 0xffffu), blo = pbf2f(b & 0xffffu);
+    const float ahi = pbf2f(a >> 16), bhi = pbf2f(b >> 16);
+    const unsigned lo = alo >= blo ? (a & 0xffffu) : (b & 0xffffu);
+    const unsigned hi = ahi >= bhi ? (a >> 16) : (b >> 16);
+    return lo | (hi << 16);
+}
+
+// zero_pad != 0: the window's out-of-image taps contribute 0 (explicit zero Pad then MaxPool,
+// resnet.py:199-204); zero_pad == 0: they are ignored (-inf padding, torch semantics).
+__global__ void maxpool_nhwc_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ y, int N, int H, int W,
+                                    int C, int Ho, int Wo, int k, int stride, int pad, int zero_pad) {
+    const int cv = C / 8;
+    const size_t total = (size_t)N * Ho * Wo * cv;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(e % cv);
+        size_t p = e / cv;
+        const int wo = (int)(p % Wo); p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        u32x4 best;
+        bool have = false;
+        bool touched_pad = false;
+        for (int dy = 0; dy < k; ++dy) {
+            const int hi = ho * stride - pad + dy;
+            for (int dx = 0; dx < k; ++dx) {
+                const int wi = wo * stride - pad + dx;
+                if ((unsigned)hi >= (unsigned)H || (unsigned)wi >= (unsigned)W) { touched_pad = true; continue; }
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(x + (((size_t)n * H + hi) * W + wi) * C + c8 * 8);
+                if (!have) { best = v; have = true; }
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) best[q] = max_bf16x2(best[q], v[q]);
+                }
+            }
+        }
+        if (!have) best = (u32x4){0u, 0u, 0u, 0u};
+        else if (zero_pad && touched_pad) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) best[q] = max_bf16x2(best[q], 0u);
+        }
+        *reinterpret_cast<u32x4 *>(y + e * 8) = best;
+    }
+}
+
+// y[n,h,w,:] = lateral[n,h,w,:] + top[n, floor(h*Ht/H), floor(w*Wt/W), :]   (nearest, F.interpolate(size=))
+__global__ void upsample_add_kernel(const uint16_t *__restrict__ lat, const uint16_t *__restrict__ top,
+                                    uint16_t *__restrict__ y, int N, int H, int W, int C, int Ht, int Wt) {
+    const int cv = C / 8;
+    const size_t total = (size_t)N * H * W * cv;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(e % cv);
+        size_t p = e / cv;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int n = (int)(p / H);
+        const int ht = min((int)(((long long)h * Ht) / H), Ht - 1), wt = min((int)(((long long)w * Wt) / W), Wt - 1);
+        const u32x4 a = *reinterpret_cast<const u32x4 *>(lat + e * 8);
+        const u32x4 b = *reinterpret_cast<const u32x4 *>(top + (((size_t)n * Ht + ht) * Wt + wt) * C + c8 * 8);
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float lo = pbf2f(a[q] & 0xffffu) + pbf2f(b[q] & 0xffffu);
+            const float hi = pbf2f(a[q] >> 16) + pbf2f(b[q] >> 16);
+            o[q] = pf2bf(lo) | (pf2bf(hi) << 16);
+        }
+        *reinterpret_cast<u32x4 *>(y + e * 8) = o;
+    }
+}
+
+// out[m, j] = float(in[m, c0 + j]) for j < cw
+__global__ void slice_cast_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, size_t M, int C, int c0,
+                                  int cw) {
+    const size_t total = M * cw;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = e / cw;
+        const int j = (int)(e % cw);
+        out[e] = pbf2f(in[m * C + c0 + j]);
+    }
+}
+
+static inline unsigned grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (unsigned)(b > 8192 ? 8192 : (b == 0 ? 1 : b));
+}
+
+}  // namespace md
+
+using namespace md;
+
+extern "C" int md_maxpool2d(MD_AOT_ARGS) {
+    if (nparam != 2) return MD_ERR_NPARAM;
+    if (!params || !extra || !ndims || !shapes || ndims[0] != 4 || ndims[1] != 4) return MD_ERR_ARG;
+    if (!dtype_is(dtypes, 0, "bfloat16") || !dtype_is(dtypes, 1, "bfloat16")) return MD_ERR_ARG;
+    const md_pool_attrs *at = (const md_pool_attrs *)extra;
+    const int N = (int)shapes[0][0], H = (int)shapes[0][1], W = (int)shapes[0][2], C = (int)shapes[0][3];
+    const int Ho = (int)shapes[1][1], Wo = (int)shapes[1][2];
+    if (C % 8 || shapes[1][3] != C || shapes[1][0] != N || at->k < 1 || at->stride < 1 || at->pad < 0) return MD_ERR_ARG;
+    if (Ho != (H + 2 * at->pad - at->k) / at->stride + 1 || Wo != (W + 2 * at->pad - at->k) / at->stride + 1)
+        return MD_ERR_ARG;
+    const size_t total = (size_t)N * Ho * Wo * (C / 8);
+    if (total == 0) return MD_OK;
+    hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)params[0], (uint16_t *)params[1], N, H, W, C, Ho, Wo, at->k, at->stride, at->pad,
+                       at->zero_pad);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+
+extern "C" int md_upsample_add(MD_AOT_ARGS) {
+    if (nparam != 3) return MD_ERR_NPARAM;
+    if (!params || !ndims || !shapes || ndims[0] != 4 || ndims[1] != 4 || ndims[2] != 4) return MD_ERR_ARG;
+    for (int i = 0; i < 3; ++i)
+        if (!dtype_is(dtypes, i, "bfloat16")) return MD_ERR_ARG;
+    const int N = (int)shapes[0][0], H = (int)shapes[0][1], W = (int)shapes[0][2], C = (int)shapes[0][3];
+    const int Ht = (int)shapes[1][1], Wt = (int)shapes[1][2];
+    if (C % 8 || shapes[1][0] != N || shapes[1][3] != C || Ht < 1 || Wt < 1) return MD_ERR_ARG;
+    for (int d = 0; d < 4; ++d)
+        if (shapes[2][d] != shapes[0][d]) return MD_ERR_ARG;
+    const size_t total = (size_t)N * H * W * (C / 8);
+    if (total == 0) return MD_OK;
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)params[0], (const uint16_t *)params[1], (uint16_t *)params[2], N, H, W, C, Ht, Wt);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+
+extern "C" int md_slice_cast(MD_AOT_ARGS) {
+    if (nparam != 2) return MD_ERR_NPARAM;
+    if (!params || !extra || !ndims || !shapes || ndims[0] < 1 || ndims[1] < 1) return MD_ERR_ARG;
+    if (!dtype_is(dtypes, 0, "bfloat16") || !dtype_is(dtypes, 1, "float32")) return MD_ERR_ARG;
+    const md_slice_attrs *at = (const md_slice_attrs *)extra;
+    const int C = (int)shapes[0][ndims[0] - 1];
+    const int64_t tot = numel(ndims, shapes, 0);
+    if (C <= 0 || at->c0 < 0 || at->width < 1 || at->c0 + at->width > C) return MD_ERR_ARG;
+    const size_t M = (size_t)(tot / C);
+    if (numel(ndims, shapes, 1) != (int64_t)(M * at->width)) return MD_ERR_ARG;
+    if (M == 0) return MD_OK;
+    hipLaunchKernelGGL(slice_cast_kernel, dim3(grid_for(M * at->width)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)params[0], (float *)params[1], M, C, at->c0, at->width);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}

@@ -1,0 +1,106 @@
+"""-m gpu: implicit-GEMM MFMA conv vs a plain PyTorch fp32 conv2d of the same op (CPU).
+
+Tolerance (stated, bf16 path): inputs and folded weights are rounded to bf16 on BOTH sides, the
+kernel accumulates in fp32 and rounds the output once to bf16 (twice when a residual is fused),
+so |err| <= 2^-8 * |y| + accumulation-order noise: rtol 1.2e-2, atol 1.2e-2 * rms(y)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs MI355X")]
+DEV = "cuda:0"
+
+CASES = [
+    # name, N, H, W, Cin, Cout, k, stride, pad, relu, residual, bn
+    ("1x1_256_64", 2, 25, 42, 256, 64, 1, 1, 0, True, False, True),
+    ("3x3_64_64", 1, 50, 84, 64, 64, 3, 1, 1, True, False, True),
+    ("3x3_s2_128", 2, 37, 41, 128, 128, 3, 2, 1, True, False, True),
+    ("stem7x7", 1, 96, 160, 3, 64, 7, 2, 3, True, False, True),
+    ("ds1x1_s2", 2, 26, 44, 256, 512, 1, 2, 0, False, False, True),
+    ("res_1x1_64_256", 1, 50, 84, 64, 256, 1, 1, 0, True, True, True),
+    ("rpn_head_15", 1, 13, 21, 256, 15, 1, 1, 0, False, False, False),
+    ("fpn3x3_256", 1, 25, 42, 256, 256, 3, 1, 1, False, False, False),
+    ("fc_12544_1024", 1, 1, 300, 12544, 1024, 1, 1, 0, True, False, False),
+    ("cout_40", 1, 20, 20, 64, 40, 3, 1, 1, True, False, True),
+    ("tiny", 1, 3, 5, 8, 8, 3, 1, 1, False, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_vs_torch_fp32(case):
+    from minddet_amd import nn_ops
+
+    name, N, H, W, Cin, Cout, k, stride, pad, relu, use_res, use_bn = case
+    g = torch.Generator().manual_seed(hash(name) % 10000)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) * (2.0 / (k * k * Cin)) ** 0.5
+    bias = None if use_bn else torch.randn((Cout,), generator=g) * 0.1
+    bn = None
+    if use_bn:
+        bn = (torch.rand((Cout,), generator=g) + 0.5, torch.randn((Cout,), generator=g) * 0.1,
+              torch.randn((Cout,), generator=g) * 0.1, torch.rand((Cout,), generator=g) + 0.5, 1e-5)
+    pc = nn_ops.pack_conv(w, bias=bias, bn=bn, stride=stride, pad=pad, relu=relu).to(DEV)
+    cin_p = pc.cin
+    x_nhwc = torch.zeros((N, H, W, cin_p))
+    x_nhwc[..., :Cin] = x.permute(0, 2, 3, 1)
+    xb = x_nhwc.to(torch.bfloat16)
+    ho, wo = nn_ops.conv_out_hw(H, W, pc)
+    res = None
+    if use_res:
+        res = torch.randn((N, ho, wo, pc.cout), generator=g).to(torch.bfloat16)
+    y = nn_ops.conv2d(xb.to(DEV), pc, residual=None if res is None else res.to(DEV))
+    torch.cuda.synchronize()
+    y = y.float().cpu()
+    # fp32 reference on the same bf16-rounded operands
+    k_real = k * k * cin_p
+    wf = pc.w.float().cpu()[:Cout, :k_real].reshape(Cout, k, k, cin_p).permute(0, 3, 1, 2)
+    ref = F.conv2d(xb.float().permute(0, 3, 1, 2), wf, pc.bias.cpu()[:Cout], stride=stride, padding=pad)
+    ref = ref.permute(0, 2, 3, 1)
+    if use_res:
+        if relu:
+            pass
+        ref = ref.to(torch.bfloat16).float() + res.float()[..., :Cout]
+    if relu:
+        ref = torch.relu(ref)
+    assert y.shape == (N, ho, wo, pc.cout)
+    got = y[..., :Cout]
+    rms = ref.pow(2).mean().sqrt().item()
+    err = (got - ref).abs()
+    tol = 1.2e-2 * ref.abs() + 1.2e-2 * rms
+    assert (err <= tol).all(), f"max err {err.max().item()} rms {rms}"
+    if pc.cout > Cout:  # padded output channels are exactly bias-free zeros (or relu(0))
+        assert (y[..., Cout:] == 0).all()
+
+
+def test_conv_linearity_property_full_size():
+    """Size-independent property at a BASELINE-sized layer (R50 layer1 conv2 at 800x1344, batch 2):
+    conv(a*x) == a*conv(x) for a power-of-two a (exact in bf16/fp32), no bias."""
+    from minddet_amd import nn_ops
+
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn((64, 64, 3, 3), generator=g) * 0.05
+    pc = nn_ops.pack_conv(w, stride=1, pad=1, relu=False).to(DEV)
+    x = torch.randn((2, 200, 336, 64), generator=g).to(torch.bfloat16).to(DEV)
+    y1 = nn_ops.conv2d(x, pc)
+    y2 = nn_ops.conv2d((x.float() * 4).to(torch.bfloat16), pc)
+    assert torch.equal((y1.float() * 4), y2.float())
+    # and a spot check against fp32 on a crop (interior pixels only)
+    xc = x[:1, 40:72, 100:132].float().cpu().permute(0, 3, 1, 2)
+    wf = pc.w.float().cpu()[:64, :576].reshape(64, 3, 3, 64).permute(0, 3, 1, 2)
+    ref = F.conv2d(xc, wf, None, padding=0).permute(0, 2, 3, 1)
+    got = y1[:1, 41:71, 101:131].float().cpu()
+    assert (got - ref).abs().max() <= 1.2e-2 * ref.abs().max()
+
+
+def test_conv_rejects_bad_args():
+    from minddet_amd import _lib, nn_ops
+
+    w = torch.randn((64, 64, 3, 3))
+    pc = nn_ops.pack_conv(w, stride=1, pad=1).to(DEV)
+    with pytest.raises(_lib.MindDetHipError):
+        nn_ops.conv2d(torch.zeros((1, 8, 8, 32), dtype=torch.bfloat16, device=DEV), pc)
+    with pytest.raises(_lib.MindDetHipError):
+        nn_ops.conv2d(torch.zeros((1, 8, 8, 64), dtype=torch.float32, device=DEV), pc)
