@@ -127,6 +127,110 @@ int md_conv2d(MD_AOT_ARGS);
  * pads Cout up to a multiple of it.  Pure function, callable without a GPU. */
 int md_conv2d_cout_tile(int cout);
 
+/* ------------------------------------------------------------------------------------------
+ * Streaming NHWC bf16 helpers between convs
+ * ------------------------------------------------------------------------------------------ */
+typedef struct md_pool_attrs {
+    int32_t k, stride, pad;
+    int32_t zero_pad; /* 1: out-of-image taps count as 0 (explicit zero Pad + MaxPool2d,
+                         centernet/src/resnet.py:199-204); 0: ignored (-inf padding) */
+} md_pool_attrs;
+/* in x[N,H,W,C] bf16 ; out y[N,Ho,Wo,C] bf16.  extra: md_pool_attrs (required). */
+int md_maxpool2d(MD_AOT_ARGS);
+/* FPN top-down step: in lateral[N,H,W,C], top[N,Ht,Wt,C] bf16 ; out y = lateral + nearest_up(top). */
+int md_upsample_add(MD_AOT_ARGS);
+typedef struct md_slice_attrs {
+    int32_t c0, width;
+} md_slice_attrs;
+/* in x[..., C] bf16 ; out y[..., width] f32 = x[..., c0:c0+width].  extra: md_slice_attrs. */
+int md_slice_cast(MD_AOT_ARGS);
+
+/* ------------------------------------------------------------------------------------------
+ * Anchor / prior generation
+ * ------------------------------------------------------------------------------------------ */
+typedef struct md_fpn_anchor_attrs {
+    int32_t num_levels, num_ratios;
+    int32_t feat_h[8], feat_w[8], stride[8];
+    float scale;
+    float ratios[16];
+} md_fpn_anchor_attrs;
+/* out anchors[sum_l H_l*W_l*A, 4] f32, levels concatenated, locations row-major, ratio fastest.
+ * Absent from the reference (dagger) -- mmdet AnchorGenerator convention. */
+int md_anchors_fpn(MD_AOT_ARGS);
+
+typedef struct md_anchor3d_attrs {
+    int32_t feat_h, feat_w, num_rot;
+    double range[6];      /* anchor_range x0,y0,z0,x1,y1,z1 */
+    double z_offset;      /* anchor_offsets[2] */
+    double size[3];       /* one size triple (w,l,h) */
+    double rotations[8];
+} md_anchor3d_attrs;
+/* create_anchors_3d_stride (pointpillars/src/core/box_np_ops.py:453-523) for ONE size:
+ * out anchors[1,H,W,1,R,7] f32, bit-identical to the numpy result (np.arange float32 fill). */
+int md_anchors_3d_stride(MD_AOT_ARGS);
+
+typedef struct md_anchor_mask_attrs {
+    int32_t grid_x, grid_y;
+    float voxel_x, voxel_y, offset_x, offset_y;
+    float area_threshold;
+} md_anchor_mask_attrs;
+/* pointpillars/src/data/preprocess.py:211-225 + box_np_ops.py:745-776:
+ * in coors[V,3] i32 (z,y,x), anchors_bv[N,4] f32 ; out area[N] f32, mask[N] u8 (area > threshold);
+ * optional workspace grid_x*grid_y*4 bytes. */
+int md_anchor_mask(MD_AOT_ARGS);
+
+/* ------------------------------------------------------------------------------------------
+ * Box codecs
+ * ------------------------------------------------------------------------------------------ */
+/* second_box_decode (pointpillars/src/core/box_ops.py:47-85): in enc[...,7] f32, anchors[A,7] f32
+ * (row i uses anchor i % A) ; out boxes[...,7] f32. */
+int md_second_box_decode(MD_AOT_ARGS);
+typedef struct md_delta2bbox_attrs {
+    float means[4], stds[4];
+    float max_ratio;      /* |log(wh_ratio_clip)| */
+    float clip_w, clip_h; /* <= 0: no clipping */
+} md_delta2bbox_attrs;
+/* in rois[n,4] f32, deltas[n,4] f32 ; out boxes[n,4] f32.  Absent from the reference (dagger). */
+int md_delta2bbox(MD_AOT_ARGS);
+
+/* ------------------------------------------------------------------------------------------
+ * Segmented top-k (ops.TopK(sorted=True) stated as a stable descending sort)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct md_topk_attrs {
+    int32_t k;        /* <= 4096 */
+    float min_score;  /* only scores > min_score are selectable; -FLT_MAX to disable */
+} md_topk_attrs;
+/* in scores[T] f32, seg_off[L+1] i32 ; out values[L,k] f32 (padded -FLT_MAX), indices[L,k] i32
+ * (relative to the segment, padded 0), count[L] i32. */
+int md_topk_segmented(MD_AOT_ARGS);
+
+/* ------------------------------------------------------------------------------------------
+ * RoIAlign over an FPN pyramid (absent from the reference, SURVEY a12: torchvision semantics)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct md_roi_align_attrs {
+    int32_t num_levels, pooled, sampling_ratio, aligned;
+    int32_t k_min, canonical_level;
+    float canonical_scale;
+    float spatial_scale[6];
+} md_roi_align_attrs;
+/* in rois[R,5] f32 (batch_idx,x1,y1,x2,y2), feat_0..feat_{L-1} [N,H_l,W_l,C] bf16 ;
+ * out pooled[R,P,P,C] bf16, level[R] i32 (pointer may be NULL). */
+int md_roi_align(MD_AOT_ARGS);
+
+/* ------------------------------------------------------------------------------------------
+ * CenterNet head decode pieces (centernet/src/decode.py, utils.py:132-157)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct md_clip_attrs {
+    float lo, hi;
+} md_clip_attrs;
+/* sigmoid then clip to [lo,hi] (default 1e-4, 1-1e-4): in x f32 ; out y f32 */
+int md_sigmoid_clip(MD_AOT_ARGS);
+/* heat * (heat == maxpool3x3_same(heat)): in heat[B,C,H,W] f32 ; out same shape */
+int md_heat_nms(MD_AOT_ARGS);
+/* in top_score[B,K] f32, top_ind2[B,K] i32 (index into C*K), cls_inds[B,C,K] i32, wh[B,2,H,W] f32,
+ *    reg[B,2,H,W] f32 or NULL ; out det[B,K,6] f32 (x1,y1,x2,y2,score,cls), inds[B,K] i32, cls[B,K] i32 */
+int md_centernet_assemble(MD_AOT_ARGS);
+
 #ifdef __cplusplus
 }
 #endif

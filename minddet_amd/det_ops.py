@@ -212,3 +212,181 @@ def circle_nms(dets, thresh):
     num = torch.empty((1,), dtype=torch.int32, device=xy.device)
     _lib.call("md_circle_nms", [xy, _thresh_tensor(thresh, xy.device), mask, idx, num])
     return order[idx[: int(num.item())].long()]
+
+
+# ----------------------------------------------------------------------------- anchors / codecs / select / roialign
+class _FpnAnchorAttrs(ctypes.Structure):
+    _fields_ = [("num_levels", ctypes.c_int32), ("num_ratios", ctypes.c_int32), ("feat_h", ctypes.c_int32 * 8),
+                ("feat_w", ctypes.c_int32 * 8), ("stride", ctypes.c_int32 * 8), ("scale", ctypes.c_float),
+                ("ratios", ctypes.c_float * 16)]
+
+
+class _Anchor3dAttrs(ctypes.Structure):
+    _fields_ = [("feat_h", ctypes.c_int32), ("feat_w", ctypes.c_int32), ("num_rot", ctypes.c_int32),
+                ("range", ctypes.c_double * 6), ("z_offset", ctypes.c_double), ("size", ctypes.c_double * 3),
+                ("rotations", ctypes.c_double * 8)]
+
+
+class _AnchorMaskAttrs(ctypes.Structure):
+    _fields_ = [("grid_x", ctypes.c_int32), ("grid_y", ctypes.c_int32), ("voxel_x", ctypes.c_float),
+                ("voxel_y", ctypes.c_float), ("offset_x", ctypes.c_float), ("offset_y", ctypes.c_float),
+                ("area_threshold", ctypes.c_float)]
+
+
+class _DeltaAttrs(ctypes.Structure):
+    _fields_ = [("means", ctypes.c_float * 4), ("stds", ctypes.c_float * 4), ("max_ratio", ctypes.c_float),
+                ("clip_w", ctypes.c_float), ("clip_h", ctypes.c_float)]
+
+
+class _TopkAttrs(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_int32), ("min_score", ctypes.c_float)]
+
+
+class _RoiAlignAttrs(ctypes.Structure):
+    _fields_ = [("num_levels", ctypes.c_int32), ("pooled", ctypes.c_int32), ("sampling_ratio", ctypes.c_int32),
+                ("aligned", ctypes.c_int32), ("k_min", ctypes.c_int32), ("canonical_level", ctypes.c_int32),
+                ("canonical_scale", ctypes.c_float), ("spatial_scale", ctypes.c_float * 6)]
+
+
+class _ClipAttrs(ctypes.Structure):
+    _fields_ = [("lo", ctypes.c_float), ("hi", ctypes.c_float)]
+
+
+FLT_MAX = 3.4028234663852886e38
+
+
+def fpn_anchors(feat_sizes, strides=(4, 8, 16, 32, 64), scale=8.0, ratios=(0.5, 1.0, 2.0), device="cuda"):
+    at = _FpnAnchorAttrs()
+    at.num_levels, at.num_ratios, at.scale = len(feat_sizes), len(ratios), float(scale)
+    total = 0
+    for i, ((h, w), s) in enumerate(zip(feat_sizes, strides)):
+        at.feat_h[i], at.feat_w[i], at.stride[i] = int(h), int(w), int(s)
+        total += h * w * len(ratios)
+    for i, r in enumerate(ratios):
+        at.ratios[i] = float(r)
+    out = torch.empty((total, 4), dtype=torch.float32, device=device)
+    _lib.call("md_anchors_fpn", [out], extra=at)
+    return out
+
+
+def create_anchors_3d_stride(feature_size, sizes=(1.6, 3.9, 1.56), anchor_strides=(0.4, 0.4, 0.0),
+                             anchor_offsets=(0.2, -39.8, -1.78), rotations=(0, math.pi / 2),
+                             anchor_range=(0.0, -39.68, -3.0, 69.12, 39.68, 1.0), dtype=torch.float32, device="cuda"):
+    """pointpillars/src/core/box_np_ops.py:453-523 on device: returns [1,H,W,1,R,7] fp32.
+    (anchor_strides / x,y offsets are unused by the reference too: it derives the stride from
+    anchor_range, :476-477.)"""
+    d, h, w = feature_size
+    assert d == 1 and len(rotations) == 2, "the reference hard-codes one z slice and two rotations (:492)"
+    at = _Anchor3dAttrs()
+    at.feat_h, at.feat_w, at.num_rot = int(h), int(w), len(rotations)
+    for i in range(6):
+        at.range[i] = float(anchor_range[i])
+    at.z_offset = float(anchor_offsets[2])
+    flat = [float(v) for v in (sizes if not isinstance(sizes[0], (list, tuple)) else sizes[0])]
+    for i in range(3):
+        at.size[i] = flat[i]
+    for i, r in enumerate(rotations):
+        at.rotations[i] = float(r)
+    out = torch.empty((1, h, w, 1, len(rotations), 7), dtype=torch.float32, device=device)
+    _lib.call("md_anchors_3d_stride", [out], extra=at)
+    return out
+
+
+def anchors_mask(coors, grid_size_xy, anchors_bv, voxel_size, pc_range, area_threshold):
+    """preprocess.py:211-225: (anchors_area f32, anchors_mask bool) for one sample."""
+    at = _AnchorMaskAttrs(int(grid_size_xy[0]), int(grid_size_xy[1]), float(voxel_size[0]), float(voxel_size[1]),
+                          float(pc_range[0]), float(pc_range[1]), float(area_threshold))
+    coors = coors.to(torch.int32).contiguous()
+    bv = _f32c(anchors_bv)
+    area = torch.empty((bv.shape[0],), dtype=torch.float32, device=bv.device)
+    mask = torch.empty((bv.shape[0],), dtype=torch.uint8, device=bv.device)
+    _lib.call("md_anchor_mask", [coors, bv, area, mask], extra=at)
+    return area, mask.bool()
+
+
+def second_box_decode(box_encodings, anchors):
+    enc, anc = _f32c(box_encodings), _f32c(anchors).reshape(-1, 7)
+    out = torch.empty_like(enc)
+    _lib.call("md_second_box_decode", [enc, anc, out])
+    return out
+
+
+def delta2bbox(rois, deltas, means=(0, 0, 0, 0), stds=(1, 1, 1, 1), max_shape=None, wh_ratio_clip=16 / 1000):
+    at = _DeltaAttrs()
+    for i in range(4):
+        at.means[i], at.stds[i] = float(means[i]), float(stds[i])
+    at.max_ratio = abs(math.log(wh_ratio_clip))
+    at.clip_h, at.clip_w = (float(max_shape[0]), float(max_shape[1])) if max_shape is not None else (0.0, 0.0)
+    rois, deltas = _f32c(rois), _f32c(deltas)
+    out = torch.empty_like(rois)
+    _lib.call("md_delta2bbox", [rois, deltas, out], extra=at)
+    return out
+
+
+def topk_segmented(scores, seg_offsets, k, min_score=None):
+    """scores [T] f32, seg_offsets [L+1] i32 (device) -> (values [L,k], indices [L,k] i32, count [L])."""
+    scores = _f32c(scores).reshape(-1)
+    L = seg_offsets.numel() - 1
+    vals = torch.empty((L, k), dtype=torch.float32, device=scores.device)
+    idx = torch.empty((L, k), dtype=torch.int32, device=scores.device)
+    cnt = torch.empty((L,), dtype=torch.int32, device=scores.device)
+    _lib.call("md_topk_segmented", [scores, seg_offsets, vals, idx, cnt],
+              extra=_TopkAttrs(int(k), -FLT_MAX if min_score is None else float(min_score)))
+    return vals, idx, cnt
+
+
+def top_k(scores2d, k):
+    """ops.TopK(sorted=True) on the last axis of a [L, n] tensor."""
+    L, n = scores2d.shape
+    off = torch.arange(0, (L + 1) * n, n, dtype=torch.int32, device=scores2d.device)
+    v, i, _ = topk_segmented(scores2d.contiguous(), off, k)
+    return v, i
+
+
+def roi_align(feats, rois, out_size=7, spatial_scales=None, sampling_ratio=2, aligned=True, k_min=2,
+              canonical_level=4, canonical_scale=224.0, return_levels=False):
+    """feats: list of [N,H,W,C] bf16 NHWC levels; rois [R,5] (batch_idx,x1,y1,x2,y2) -> [R,P,P,C] bf16."""
+    L = len(feats)
+    at = _RoiAlignAttrs()
+    at.num_levels, at.pooled, at.sampling_ratio, at.aligned = L, int(out_size), int(sampling_ratio), int(aligned)
+    at.k_min, at.canonical_level, at.canonical_scale = int(k_min), int(canonical_level), float(canonical_scale)
+    for i in range(L):
+        at.spatial_scale[i] = float(spatial_scales[i])
+    rois = _f32c(rois)
+    R, C = rois.shape[0], feats[0].shape[3]
+    out = torch.empty((R, out_size, out_size, C), dtype=torch.bfloat16, device=rois.device)
+    lv = torch.empty((R,), dtype=torch.int32, device=rois.device) if return_levels else None
+    _lib.call("md_roi_align", [rois] + list(feats) + [out, lv], extra=at)
+    return (out, lv) if return_levels else out
+
+
+def sigmoid_clip(x, lo=1e-4, hi=1 - 1e-4):
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    _lib.call("md_sigmoid_clip", [x, y], extra=_ClipAttrs(lo, hi))
+    return y
+
+
+class DetectionDecode:
+    """Mirror of centernet/src/decode.py:123-196 (NMS :40-64, GatherTopK :90-109): feature dict with
+    'hm' [B,C,H,W] (already sigmoid+clip), 'wh', 'reg' [B,2,H,W] fp32 NCHW -> detections [B,K,6]."""
+
+    def __init__(self, reg_offset=True, K=100):
+        self.reg_offset, self.K = reg_offset, K
+
+    def __call__(self, feature, return_indices=False):
+        hm, wh = _f32c(feature["hm"]), _f32c(feature["wh"])
+        reg = _f32c(feature["reg"]) if self.reg_offset else None
+        B, C, H, W = hm.shape
+        K = self.K
+        heat = torch.empty_like(hm)
+        _lib.call("md_heat_nms", [hm, heat])
+        v1, i1 = top_k(heat.view(B * C, H * W), K)           # per-class top-K  (decode.py:96)
+        v2, i2 = top_k(v1.view(B, C * K), K)                 # global top-K     (decode.py:101)
+        det = torch.empty((B, K, 6), dtype=torch.float32, device=hm.device)
+        inds = torch.empty((B, K), dtype=torch.int32, device=hm.device)
+        cls = torch.empty((B, K), dtype=torch.int32, device=hm.device)
+        _lib.call("md_centernet_assemble", [v2, i2, i1.view(B, C, K), wh, reg, det, inds, cls])
+        return (det, inds, cls) if return_indices else det
+
+    construct = __call__

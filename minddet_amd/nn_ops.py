@@ -95,3 +95,35 @@ def linear(x2d, pc, relu=None):
     r, c = x2d.shape
     y = conv2d(x2d.view(r, 1, 1, c), pc, relu=relu)
     return y.view(r, pc.cout)
+
+
+class _PoolAttrs(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32), ("zero_pad", ctypes.c_int32)]
+
+
+class _SliceAttrs(ctypes.Structure):
+    _fields_ = [("c0", ctypes.c_int32), ("width", ctypes.c_int32)]
+
+
+def maxpool2d(x, k=3, stride=2, pad=1, zero_pad=True):
+    """NHWC bf16 max-pool. zero_pad=True is the reference stem (explicit zero Pad then
+    MaxPool2d(3,2), centernet/src/resnet.py:199-204)."""
+    n, h, w, c = x.shape
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    y = torch.empty((n, ho, wo, c), dtype=torch.bfloat16, device=x.device)
+    _lib.call("md_maxpool2d", [x, y], extra=_PoolAttrs(k, stride, pad, int(zero_pad)))
+    return y
+
+
+def upsample_add(lateral, top):
+    """FPN top-down: lateral + nearest-upsampled top (to lateral's size)."""
+    y = torch.empty_like(lateral)
+    _lib.call("md_upsample_add", [lateral, top, y])
+    return y
+
+
+def slice_cast(x, c0, width):
+    """x[..., c0:c0+width] (bf16) -> fp32 contiguous."""
+    y = torch.empty(tuple(x.shape[:-1]) + (width,), dtype=torch.float32, device=x.device)
+    _lib.call("md_slice_cast", [x, y], extra=_SliceAttrs(c0, width))
+    return y
