@@ -1,0 +1,155 @@
+"""bench.py -- images/sec of the Faster R-CNN R50-FPN 800x1344 bf16 inference hot path on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--batch B]
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the whole path (backbone + FPN + RPN + proposals + RoIAlign + box head +
+class-wise NMS + packing) over one batch of synthetic COCO-shaped images already resident in HBM,
+followed, when N > 1, by the single all_gather of the padded detections.  Images are
+sharded across ranks (weak scaling: B images per GPU); value = N*B*K / max-over-ranks time.
+
+The JSON line also carries
+  roofline     -- the dominant kernel (conv_igemm, MFMA-bound): algorithmic FLOPs of every conv/FC
+                  launch in the timed region / the sum of their durations, each launch bracketed by
+                  HIP events on the launch stream; peak = 2.5 PFLOP/s dense bf16.
+  cpu_baseline -- the oracle's plain fp32 torch-CPU restatement of the same graph (oracle/nets.py)
+                  timed on this host's cores on ONE image (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (guide: ~2.5 PF)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--config", default=os.path.join(ROOT, "configs", "faster_rcnn", "faster_rcnn_r50_fpn.py"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from minddet.models import Config, build_detector
+    from minddet_amd import _lib, nn_ops
+    from minddet_amd.data import synthetic_images
+    from minddet_amd.shard import gather_detections
+
+    cfg = Config.fromfile(args.config)
+    model = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(dev)
+    H, W = cfg.data.input_hw
+    B = args.batch
+    images = synthetic_images(B, H, W, seed=20240317 + rank, device=dev)
+
+    # ---- per-conv event instrumentation (roofline of the dominant kernel)
+    records = []
+    orig_conv2d = nn_ops.conv2d
+
+    def timed_conv2d(x, pc, residual=None, relu=None, out=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig_conv2d(x, pc, residual=residual, relu=relu, out=out)
+        e1.record()
+        n, ho, wo, _ = y.shape
+        records.append((e0, e1, 2.0 * n * ho * wo * pc.cout * pc.cin_real * pc.kh * pc.kw, tuple(x.shape), pc.cout, pc.kh))
+        return y
+
+    def step():
+        dets, count = model.forward(images)
+        if world > 1:
+            return gather_detections(dets, count)
+        return dets, count
+
+    for _ in range(args.warmup):
+        step()
+    instrument = not args.no_roofline
+    if instrument:
+        nn_ops.conv2d = timed_conv2d
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    nn_ops.conv2d = orig_conv2d
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roofline = None
+    if instrument and records:
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in records)
+        tot_fl = sum(r[2] for r in records)
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (implicit-GEMM conv/FC, all launches)",
+                    "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                    "traffic": None, "launches_per_step": len(records) // max(args.steps, 1),
+                    "avg_launch_us": round(tot_ms * 1e3 / len(records), 2),
+                    "conv_ms_per_step": round(tot_ms / max(args.steps, 1), 3),
+                    "algorithmic_gflop_per_step": round(tot_fl / max(args.steps, 1) / 1e9, 1)}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import nets
+
+        torch.set_num_threads(os.cpu_count() or 1)
+        x1 = images[:1].float().cpu()
+        nets.faster_rcnn_forward(model, x1[:, :256, :256], quant=False)  # warm-up on a crop
+        tc = time.perf_counter()
+        n_img = 0
+        while n_img < 1 or (time.perf_counter() - tc < 10.0 and n_img < 4):
+            nets.faster_rcnn_forward(model, x1, quant=False)
+            n_img += 1
+        tcpu = time.perf_counter() - tc
+        cpu_baseline = {"value": round(n_img / tcpu, 4), "unit": "images/sec", "cores": torch.get_num_threads(),
+                        "kind": "port",
+                        "sample": f"{n_img} image(s) 800x1344, oracle/nets.py fp32 torch-CPU restatement of the same graph "
+                                  "(MindSpore-CPU is not installable here; BASELINE.md section 3)"}
+
+    if rank == 0:
+        total_images = world * B * args.steps
+        line = {
+            "metric": "images/sec, Faster R-CNN R50-FPN inference, COCO-shaped 1333x800 (padded 800x1344)",
+            "value": round(total_images / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "faster_rcnn_r50_fpn_800x1344 (BASELINE.json configs[2])", "batch_per_gpu": B,
+                       "global_batch": world * B, "parallelism": f"dp{world} (image sharding + all_gather of detections)",
+                       "gmac_per_image": round(model.macs_per_image(H, W) / 1e9, 1), "weights": "random init, seed 7"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "lib": os.path.relpath(_lib.LIB_PATH, ROOT),
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

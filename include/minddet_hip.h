@@ -231,6 +231,40 @@ int md_heat_nms(MD_AOT_ARGS);
  *    reg[B,2,H,W] f32 or NULL ; out det[B,K,6] f32 (x1,y1,x2,y2,score,cls), inds[B,K] i32, cls[B,K] i32 */
 int md_centernet_assemble(MD_AOT_ARGS);
 
+/* ------------------------------------------------------------------------------------------
+ * Two-stage (Faster R-CNN style) glue between conv stacks and detection ops.  Absent from the
+ * reference; mmdet/torchvision public conventions; pinned by oracle/pipeline.py only.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct md_rpn_decode_attrs {
+    int32_t num_anchors;          /* A: head channels [0,A) objectness, [A,5A) deltas (a*4+j) */
+    md_delta2bbox_attrs decode;
+} md_rpn_decode_attrs;
+/* in head[B,H,W,Cp] bf16, anchors[H*W*A,4] f32, idx[B,k] i32, cnt[B] i32 ;
+ * out boxes[B,k,4] f32 (0 past cnt), scores[B,k] f32 = sigmoid(logit) (-FLT_MAX past cnt) */
+int md_rpn_decode(MD_AOT_ARGS);
+/* in boxes[L,B,k,4] f32, scores[L,B,k] f32, keep[L,B,k] u8 ; out mboxes[B,L*k,4], mscores[B,L*k]
+ * (score -FLT_MAX where suppressed) */
+int md_rpn_merge(MD_AOT_ARGS);
+/* in mboxes[B,P,4] f32, topv[B,post] f32, topi[B,post] i32, cnt[B] i32 ;
+ * out rois[B*post,5] f32 (batch_idx,x1,y1,x2,y2; zero box past cnt), roi_scores[B*post] f32 */
+int md_make_rois(MD_AOT_ARGS);
+typedef struct md_rcnn_attrs {
+    int32_t num_classes;  /* nc foreground classes; logits [0,nc] with background LAST */
+    int32_t reg_offset;   /* first channel of the 4*nc class-specific deltas */
+    float score_thr;
+    md_delta2bbox_attrs decode;
+} md_rcnn_attrs;
+/* in cls_reg[R,Cp] bf16, roi_cnt[B] i32 ; out cand[B, (R/B)*nc] f32 = softmax prob if > score_thr
+ * and the RoI slot is valid, else -FLT_MAX */
+int md_rcnn_scores(MD_AOT_ARGS);
+/* in cls_reg[R,Cp] bf16, rois[R,5] f32, sel_idx[B,npre] i32 (j*nc + c), sel_cnt[B] i32 ;
+ * out boxes[B,npre,4] f32, labels[B,npre] i32 (-1 past cnt) */
+int md_rcnn_decode_selected(MD_AOT_ARGS);
+/* class-wise merge + packing (shape of centernet/src/post_process.py:36-61):
+ * in boxes[B,npre,4] f32, scores[B,npre] f32, labels[B,npre] i32, keep_idx[B,npre] i32, num[B] i32 ;
+ * out dets[B,max_det,6] f32 (x1,y1,x2,y2,score,label; zero padded), count[B] i32 */
+int md_pack_detections(MD_AOT_ARGS);
+
 #ifdef __cplusplus
 }
 #endif

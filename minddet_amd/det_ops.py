@@ -323,13 +323,13 @@ def delta2bbox(rois, deltas, means=(0, 0, 0, 0), stds=(1, 1, 1, 1), max_shape=No
     return out
 
 
-def topk_segmented(scores, seg_offsets, k, min_score=None):
+def topk_segmented(scores, seg_offsets, k, min_score=None, out_cnt=None):
     """scores [T] f32, seg_offsets [L+1] i32 (device) -> (values [L,k], indices [L,k] i32, count [L])."""
     scores = _f32c(scores).reshape(-1)
     L = seg_offsets.numel() - 1
     vals = torch.empty((L, k), dtype=torch.float32, device=scores.device)
     idx = torch.empty((L, k), dtype=torch.int32, device=scores.device)
-    cnt = torch.empty((L,), dtype=torch.int32, device=scores.device)
+    cnt = out_cnt if out_cnt is not None else torch.empty((L,), dtype=torch.int32, device=scores.device)
     _lib.call("md_topk_segmented", [scores, seg_offsets, vals, idx, cnt],
               extra=_TopkAttrs(int(k), -FLT_MAX if min_score is None else float(min_score)))
     return vals, idx, cnt
@@ -390,3 +390,77 @@ class DetectionDecode:
         return (det, inds, cls) if return_indices else det
 
     construct = __call__
+
+
+# ----------------------------------------------------------------------------- two-stage glue
+class _RpnDecodeAttrs(ctypes.Structure):
+    _fields_ = [("num_anchors", ctypes.c_int32), ("decode", _DeltaAttrs)]
+
+
+class _RcnnAttrs(ctypes.Structure):
+    _fields_ = [("num_classes", ctypes.c_int32), ("reg_offset", ctypes.c_int32), ("score_thr", ctypes.c_float),
+                ("decode", _DeltaAttrs)]
+
+
+def _decode_attrs(means, stds, img_hw, wh_ratio_clip=16 / 1000):
+    at = _DeltaAttrs()
+    for i in range(4):
+        at.means[i], at.stds[i] = float(means[i]), float(stds[i])
+    at.max_ratio = abs(math.log(wh_ratio_clip))
+    at.clip_h, at.clip_w = (float(img_hw[0]), float(img_hw[1])) if img_hw is not None else (0.0, 0.0)
+    return at
+
+
+def rpn_decode(head, anchors, idx, cnt, num_anchors, img_hw, means=(0, 0, 0, 0), stds=(1, 1, 1, 1), out_boxes=None,
+               out_scores=None):
+    B, k = idx.shape
+    if out_boxes is None:
+        out_boxes = torch.empty((B, k, 4), dtype=torch.float32, device=head.device)
+    if out_scores is None:
+        out_scores = torch.empty((B, k), dtype=torch.float32, device=head.device)
+    at = _RpnDecodeAttrs(int(num_anchors), _decode_attrs(means, stds, img_hw))
+    _lib.call("md_rpn_decode", [head, anchors, idx, cnt, out_boxes, out_scores], extra=at)
+    return out_boxes, out_scores
+
+
+def rpn_merge(boxes, scores, keep):
+    L, B, k = scores.shape
+    mboxes = torch.empty((B, L * k, 4), dtype=torch.float32, device=boxes.device)
+    mscores = torch.empty((B, L * k), dtype=torch.float32, device=boxes.device)
+    _lib.call("md_rpn_merge", [boxes, scores, keep, mboxes, mscores])
+    return mboxes, mscores
+
+
+def make_rois(mboxes, topv, topi, cnt):
+    B, post = topv.shape
+    rois = torch.empty((B * post, 5), dtype=torch.float32, device=mboxes.device)
+    rs = torch.empty((B * post,), dtype=torch.float32, device=mboxes.device)
+    _lib.call("md_make_rois", [mboxes, topv, topi, cnt, rois, rs])
+    return rois, rs
+
+
+def rcnn_scores(cls_reg, roi_cnt, num_classes, score_thr):
+    R = cls_reg.shape[0]
+    B = roi_cnt.numel()
+    cand = torch.empty((B, (R // B) * num_classes), dtype=torch.float32, device=cls_reg.device)
+    at = _RcnnAttrs(int(num_classes), 0, float(score_thr), _DeltaAttrs())
+    _lib.call("md_rcnn_scores", [cls_reg, roi_cnt, cand], extra=at)
+    return cand
+
+
+def rcnn_decode_selected(cls_reg, rois, sel_idx, sel_cnt, num_classes, reg_offset, img_hw, means=(0, 0, 0, 0),
+                         stds=(0.1, 0.1, 0.2, 0.2)):
+    B, npre = sel_idx.shape
+    boxes = torch.empty((B, npre, 4), dtype=torch.float32, device=cls_reg.device)
+    labels = torch.empty((B, npre), dtype=torch.int32, device=cls_reg.device)
+    at = _RcnnAttrs(int(num_classes), int(reg_offset), 0.0, _decode_attrs(means, stds, img_hw))
+    _lib.call("md_rcnn_decode_selected", [cls_reg, rois, sel_idx, sel_cnt, boxes, labels], extra=at)
+    return boxes, labels
+
+
+def pack_detections(boxes, scores, labels, keep_idx, num, max_det):
+    B = scores.shape[0]
+    dets = torch.empty((B, max_det, 6), dtype=torch.float32, device=boxes.device)
+    count = torch.empty((B,), dtype=torch.int32, device=boxes.device)
+    _lib.call("md_pack_detections", [boxes, scores, labels, keep_idx, num, dets, count])
+    return dets, count

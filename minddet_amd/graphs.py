@@ -1,0 +1,377 @@
+"""Inference graphs as sequences of libminddet_hip.so calls (NHWC bf16 activations).
+
+Reference-present graphs (cited per class) and the build-authored two-stage graph (absent from the
+reference, SURVEY 0.2 -- standard public architecture, "parity unpinned").  Each module keeps its
+fp32 parameters in the reference's layout (`.weight [Cout,Cin,kh,kw]`, `.bn = (gamma, beta, mean,
+var, eps)`) so that the CPU oracle (oracle/nets.py) can run the same graph, and a packed bf16 copy
+for the kernels.  Random init follows SURVEY 8(d): He-normal std = sqrt(2/(k*k*Cout))
+(centernet/src/resnet.py:210-213), BN gamma=1, beta=0, mean~N(0,0.1), var~U(0.5,1.5).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import det_ops, nn_ops
+from .registry import BACKBONES, DETECTORS, HEADS, NECKS, ROI_HEAD, build_backbone, build_head, build_neck, build_roi_head
+
+
+class ParamInit:
+    """Deterministic parameter source (numpy Generator, seed 7 by default)."""
+
+    def __init__(self, seed=7):
+        self.rng = np.random.default_rng(seed)
+
+    def conv(self, cout, cin, k, std=None):
+        std = math.sqrt(2.0 / (k * k * cout)) if std is None else std
+        return torch.from_numpy(self.rng.normal(0.0, std, (cout, cin, k, k)).astype(np.float32))
+
+    def bn(self, c, eps=1e-5):
+        return (torch.ones(c), torch.zeros(c), torch.from_numpy(self.rng.normal(0, 0.1, c).astype(np.float32)),
+                torch.from_numpy(self.rng.uniform(0.5, 1.5, c).astype(np.float32)), eps)
+
+    def bias(self, c, value=None, std=0.01):
+        if value is not None:
+            return torch.full((c,), float(value))
+        return torch.from_numpy(self.rng.normal(0, std, c).astype(np.float32))
+
+
+class ConvModule:
+    """Conv2d [+ BatchNorm2d(eval)] [+ ReLU] -> one md_conv2d call."""
+
+    def __init__(self, init, cin, cout, k, stride=1, pad=0, bn=True, relu=True, bias=False, bn_eps=1e-5, std=None,
+                 bias_value=None):
+        self.cin, self.cout, self.k, self.stride, self.pad, self.relu = cin, cout, k, stride, pad, relu
+        self.weight = init.conv(cout, cin, k, std)
+        self.bn = init.bn(cout, bn_eps) if bn else None
+        self.bias = init.bias(cout, bias_value) if bias else None
+        self.packed = None
+
+    def to(self, device):
+        self.packed = nn_ops.pack_conv(self.weight, bias=self.bias, bn=self.bn, stride=self.stride, pad=self.pad,
+                                       relu=self.relu).to(device)
+        return self
+
+    def __call__(self, x, residual=None):
+        return nn_ops.conv2d(x, self.packed, residual=residual)
+
+    def macs(self, ho, wo):
+        return ho * wo * self.cout * self.cin * self.k * self.k
+
+
+# ----------------------------------------------------------------------------- ResNet (centernet/src/resnet.py)
+class BasicBlock:
+    """centernet/src/resnet.py:109-136"""
+    expansion = 1
+
+    def __init__(self, init, inplanes, planes, stride=1, downsample=None):
+        self.conv1 = ConvModule(init, inplanes, planes, 3, stride, 1)
+        self.conv2 = ConvModule(init, planes, planes, 3, 1, 1, relu=True)  # ReLU applied after the residual add
+        self.downsample = downsample
+
+    def modules(self):
+        return [self.conv1, self.conv2] + ([self.downsample] if self.downsample else [])
+
+    def __call__(self, x):
+        residual = self.downsample(x) if self.downsample is not None else x
+        out = self.conv1(x)
+        return self.conv2(out, residual=residual)
+
+
+class Bottleneck:
+    """centernet/src/resnet.py:139-178 (stride on the 3x3 conv)"""
+    expansion = 4
+
+    def __init__(self, init, inplanes, planes, stride=1, downsample=None):
+        self.conv1 = ConvModule(init, inplanes, planes, 1)
+        self.conv2 = ConvModule(init, planes, planes, 3, stride, 1)
+        self.conv3 = ConvModule(init, planes, planes * 4, 1, relu=True)  # ReLU after the residual add
+        self.downsample = downsample
+
+    def modules(self):
+        return [self.conv1, self.conv2, self.conv3] + ([self.downsample] if self.downsample else [])
+
+    def __call__(self, x):
+        residual = self.downsample(x) if self.downsample is not None else x
+        out = self.conv2(self.conv1(x))
+        return self.conv3(out, residual=residual)
+
+
+@BACKBONES.register_module
+class ResNet:
+    """centernet/src/resnet.py:181-252: 7x7/2 stem + BN + ReLU, zero-pad + MaxPool(3,2), 4 stages;
+    returns (C2, C3, C4, C5).  depth 18/34 -> BasicBlock, 50/101 -> Bottleneck."""
+    SETTINGS = {18: (BasicBlock, [2, 2, 2, 2]), 34: (BasicBlock, [3, 4, 6, 3]), 50: (Bottleneck, [3, 4, 6, 3]),
+                101: (Bottleneck, [3, 4, 23, 3])}
+
+    def __init__(self, depth=50, base_width=64, seed=7, init=None, layers=None):
+        block, default_layers = self.SETTINGS[depth]
+        layers = layers or default_layers
+        init = init or ParamInit(seed)
+        self.block, self.inplanes = block, base_width
+        self.conv1 = ConvModule(init, 3, base_width, 7, 2, 3)
+        self.stages = []
+        for i, n in enumerate(layers):
+            self.stages.append(self._make_layer(init, block, base_width * (2 ** i), n, 1 if i == 0 else 2))
+        self.out_channels = [base_width * (2 ** i) * block.expansion for i in range(4)]
+
+    def _make_layer(self, init, block, planes, blocks, stride):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = ConvModule(init, self.inplanes, planes * block.expansion, 1, stride, 0, relu=False)
+        layers = [block(init, self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(init, self.inplanes, planes))
+        return layers
+
+    def modules(self):
+        out = [self.conv1]
+        for st in self.stages:
+            for b in st:
+                out += b.modules()
+        return out
+
+    def to(self, device):
+        for m in self.modules():
+            m.to(device)
+        return self
+
+    def __call__(self, x):
+        x = self.conv1(x)
+        x = nn_ops.maxpool2d(x, 3, 2, 1, zero_pad=True)
+        outs = []
+        for st in self.stages:
+            for b in st:
+                x = b(x)
+            outs.append(x)
+        return tuple(outs)
+
+
+# ----------------------------------------------------------------------------- FPN / RPN / RoI head (build-authored)
+@NECKS.register_module
+class FPN:
+    """Lin et al. 2017: 1x1 laterals, top-down nearest upsample + add, 3x3 output convs, extra level by
+    stride-2 subsampling (max_pool k=1 s=2) of the last output.  parity unpinned."""
+
+    def __init__(self, in_channels, out_channels=256, num_outs=5, seed=11, init=None):
+        init = init or ParamInit(seed)
+        self.lateral = [ConvModule(init, c, out_channels, 1, bn=False, relu=False, bias=True) for c in in_channels]
+        self.output = [ConvModule(init, out_channels, out_channels, 3, 1, 1, bn=False, relu=False, bias=True)
+                       for _ in in_channels]
+        self.num_outs = num_outs
+
+    def modules(self):
+        return self.lateral + self.output
+
+    def to(self, device):
+        for m in self.modules():
+            m.to(device)
+        return self
+
+    def __call__(self, feats):
+        lats = [l(f) for l, f in zip(self.lateral, feats)]
+        for i in range(len(lats) - 1, 0, -1):
+            lats[i - 1] = nn_ops.upsample_add(lats[i - 1], lats[i])
+        outs = [o(l) for o, l in zip(self.output, lats)]
+        while len(outs) < self.num_outs:
+            outs.append(nn_ops.maxpool2d(outs[-1], 1, 2, 0, zero_pad=False))
+        return outs
+
+
+@HEADS.register_module
+class RPNHead:
+    """Shared 3x3 conv + ReLU, then one fused 1x1 conv producing [A objectness | 4A deltas] channels.
+    Proposal generation: per level top-k (nms_pre) on the logits, delta2bbox + clip, NMS (iou_thr),
+    per image top-`max_per_img` across levels.  parity unpinned (absent from the reference)."""
+
+    def __init__(self, in_channels=256, feat_channels=256, strides=(4, 8, 16, 32, 64), scale=8.0,
+                 ratios=(0.5, 1.0, 2.0), nms_pre=1000, max_per_img=1000, nms_thr=0.7, seed=13, init=None):
+        init = init or ParamInit(seed)
+        self.A = len(ratios)
+        self.conv = ConvModule(init, in_channels, feat_channels, 3, 1, 1, bn=False, relu=True, bias=True, std=0.01)
+        self.out = ConvModule(init, feat_channels, 5 * self.A, 1, bn=False, relu=False, bias=True, std=0.01)
+        self.strides, self.scale, self.ratios = tuple(strides), scale, tuple(ratios)
+        self.nms_pre, self.max_per_img, self.nms_thr = nms_pre, max_per_img, nms_thr
+        self._cache = {}
+
+    def modules(self):
+        return [self.conv, self.out]
+
+    def to(self, device):
+        for m in self.modules():
+            m.to(device)
+        return self
+
+    def _static(self, feats, img_hw):
+        B = feats[0].shape[0]
+        sizes = tuple((f.shape[1], f.shape[2]) for f in feats)
+        key = (B, sizes, img_hw)
+        if key not in self._cache:
+            dev = feats[0].device
+            anchors = det_ops.fpn_anchors(sizes, self.strides, self.scale, self.ratios, device=dev)
+            per, offs, o = [], [], 0
+            for (h, w) in sizes:
+                n = h * w * self.A
+                per.append(anchors[o:o + n])
+                offs.append(torch.arange(0, (B + 1) * n, n, dtype=torch.int32, device=dev))
+                o += n
+            L, k = len(sizes), self.nms_pre
+            self._cache[key] = dict(anchors=per, seg=offs,
+                                    merged_seg=torch.arange(0, (B + 1) * L * k, L * k, dtype=torch.int32, device=dev))
+        return self._cache[key]
+
+    def __call__(self, feats, img_hw):
+        st = self._static(feats, img_hw)
+        B, L, k, A = feats[0].shape[0], len(feats), self.nms_pre, self.A
+        dev = feats[0].device
+        boxes = torch.empty((L, B, k, 4), dtype=torch.float32, device=dev)
+        scores = torch.empty((L, B, k), dtype=torch.float32, device=dev)
+        counts = torch.empty((L, B), dtype=torch.int32, device=dev)
+        heads = []
+        for l, f in enumerate(feats):
+            head = self.out(self.conv(f))                       # [B,H,W,16]
+            heads.append(head)
+            logits = nn_ops.slice_cast(head, 0, A)              # [B,H,W,A] fp32
+            _, idx, cnt = det_ops.topk_segmented(logits, st["seg"][l], k, out_cnt=counts[l])
+            det_ops.rpn_decode(head, st["anchors"][l], idx, cnt, A, img_hw, out_boxes=boxes[l], out_scores=scores[l])
+        keep, _, _ = det_ops.nms_aligned(boxes.view(L * B, k, 4), self.nms_thr, mode=det_ops.NMS_MODE_STRICT,
+                                         count=counts.view(-1))
+        mboxes, mscores = det_ops.rpn_merge(boxes, scores, keep.view(L, B, k))
+        topv, topi, cnt = det_ops.topk_segmented(mscores, st["merged_seg"], self.max_per_img)
+        rois, roi_scores = det_ops.make_rois(mboxes, topv, topi, cnt)
+        return rois, roi_scores, cnt, dict(heads=heads, boxes=boxes, scores=scores, counts=counts, keep=keep,
+                                           mboxes=mboxes, mscores=mscores)
+
+
+@ROI_HEAD.register_module
+class StandardRoIHead:
+    """RoIAlign 7x7 over P2..P5 -> FC 1024 -> FC 1024 -> fused [cls (nc+1) | reg (4 nc)] FC, softmax,
+    class-specific delta2bbox, score threshold, class-wise NMS, top max_per_img.  parity unpinned."""
+
+    def __init__(self, in_channels=256, fc_channels=1024, num_classes=80, roi_size=7, sampling_ratio=2,
+                 featmap_strides=(4, 8, 16, 32), score_thr=0.05, nms_thr=0.5, max_per_img=100, nms_pre=2048,
+                 seed=17, init=None):
+        init = init or ParamInit(seed)
+        self.nc, self.P, self.C = num_classes, roi_size, in_channels
+        k_in = in_channels * roi_size * roi_size
+        # FC weights are stored in the conv layout [Cout, Cin, 1, 1]; fc1's Cin axis is ordered (h, w, c) to
+        # match the NHWC RoIAlign output flattened as-is.
+        self.fc1 = ConvModule(init, k_in, fc_channels, 1, bn=False, relu=True, bias=True, std=math.sqrt(2.0 / k_in))
+        self.fc2 = ConvModule(init, fc_channels, fc_channels, 1, bn=False, relu=True, bias=True,
+                              std=math.sqrt(2.0 / fc_channels))
+        self.reg_offset = (num_classes + 1 + 7) // 8 * 8
+        n_out = self.reg_offset + 4 * num_classes
+        self.fc_out = ConvModule(init, fc_channels, n_out, 1, bn=False, relu=False, bias=True, std=0.01)
+        # channels [nc+1, reg_offset) are alignment padding: zero their weights so they stay inert
+        self.fc_out.weight[num_classes + 1:self.reg_offset] = 0
+        self.fc_out.bias[num_classes + 1:self.reg_offset] = 0
+        # class logits get a wider init so that the synthetic benchmark has above-threshold candidates
+        self.fc_out.weight[:num_classes + 1] *= 20.0
+        self.strides, self.sampling = tuple(featmap_strides), sampling_ratio
+        self.score_thr, self.nms_thr, self.max_per_img, self.nms_pre = score_thr, nms_thr, max_per_img, nms_pre
+        self._cache = {}
+
+    def modules(self):
+        return [self.fc1, self.fc2, self.fc_out]
+
+    def to(self, device):
+        for m in self.modules():
+            m.to(device)
+        return self
+
+    def __call__(self, feats, rois, roi_cnt, img_hw):
+        B = feats[0].shape[0]
+        R = rois.shape[0]
+        post = R // B
+        dev = rois.device
+        pooled = det_ops.roi_align(list(feats[:len(self.strides)]), rois, self.P, [1.0 / s for s in self.strides],
+                                   self.sampling, True)
+        x = nn_ops.linear(pooled.view(R, self.P * self.P * self.C), self.fc1.packed)
+        x = nn_ops.linear(x, self.fc2.packed)
+        cls_reg = nn_ops.linear(x, self.fc_out.packed)
+        cand = det_ops.rcnn_scores(cls_reg, roi_cnt, self.nc, self.score_thr)
+        key = (B, post)
+        if key not in self._cache:
+            self._cache[key] = torch.arange(0, (B + 1) * post * self.nc, post * self.nc, dtype=torch.int32, device=dev)
+        sv, si, sc = det_ops.topk_segmented(cand, self._cache[key], self.nms_pre)
+        boxes, labels = det_ops.rcnn_decode_selected(cls_reg, rois, si, sc, self.nc, self.reg_offset, img_hw)
+        keep, kidx, num = det_ops.nms_aligned(boxes, self.nms_thr, mode=det_ops.NMS_MODE_STRICT, count=sc, group=labels,
+                                              max_output=self.max_per_img)
+        dets, count = det_ops.pack_detections(boxes, sv, labels, kidx, num, self.max_per_img)
+        return dets, count, dict(pooled=pooled, cls_reg=cls_reg, cand=cand, sel_scores=sv, sel_idx=si, sel_cnt=sc,
+                                 boxes=boxes, labels=labels, keep=keep)
+
+
+@DETECTORS.register_module
+class FasterRCNN:
+    """Two-stage detector: backbone -> neck -> rpn_head -> roi_head.  `forward(images)` takes
+    [B,H,W,8] bf16 NHWC (RGB in channels 0..2, 5 zero channels) and returns (dets [B,max_det,6], count [B])."""
+
+    def __init__(self, backbone, neck, rpn_head, roi_head, train_cfg=None, test_cfg=None):
+        self.backbone = build_backbone(backbone)
+        neck = dict(neck)
+        neck.setdefault("in_channels", self.backbone.out_channels)
+        self.neck = build_neck(neck)
+        self.rpn_head = build_head(rpn_head)
+        self.roi_head = build_roi_head(roi_head)
+        self.test_cfg = test_cfg
+
+    def to(self, device):
+        for m in (self.backbone, self.neck, self.rpn_head, self.roi_head):
+            m.to(device)
+        return self
+
+    def conv_modules(self):
+        return self.backbone.modules() + self.neck.modules() + self.rpn_head.modules() + self.roi_head.modules()
+
+    def extract_feat(self, images):
+        return self.neck(self.backbone(images))
+
+    def forward(self, images, return_aux=False):
+        img_hw = (images.shape[1], images.shape[2])
+        feats = self.extract_feat(images)
+        rois, roi_scores, roi_cnt, aux_rpn = self.rpn_head(feats, img_hw)
+        dets, count, aux_roi = self.roi_head(feats, rois, roi_cnt, img_hw)
+        if return_aux:
+            return dets, count, dict(feats=feats, rois=rois, roi_scores=roi_scores, roi_cnt=roi_cnt, rpn=aux_rpn, roi=aux_roi)
+        return dets, count
+
+    __call__ = forward
+
+    def macs_per_image(self, h, w, num_rois=None):
+        """Algorithmic MACs (SURVEY 8d formula) of every conv/FC for one h x w image."""
+        total, hh, ww = 0, h, w
+        bb = self.backbone
+
+        def out_hw(m, hh, ww):
+            return (hh + 2 * m.pad - m.k) // m.stride + 1, (ww + 2 * m.pad - m.k) // m.stride + 1
+
+        hh, ww = out_hw(bb.conv1, hh, ww)
+        total += bb.conv1.macs(hh, ww)
+        hh, ww = (hh + 2 - 3) // 2 + 1, (ww + 2 - 3) // 2 + 1
+        sizes = []
+        for st in bb.stages:
+            for b in st:
+                h_in, w_in = hh, ww
+                for m in b.modules():
+                    if m is b.downsample:
+                        ho, wo = out_hw(m, h_in, w_in)
+                        total += m.macs(ho, wo)
+                    else:
+                        hh, ww = out_hw(m, hh, ww)
+                        total += m.macs(hh, ww)
+            sizes.append((hh, ww))
+        for l, (a, b_) in zip(self.neck.lateral, sizes):
+            total += l.macs(a, b_)
+        for o, (a, b_) in zip(self.neck.output, sizes):
+            total += o.macs(a, b_)
+        lv = list(sizes)
+        while len(lv) < self.neck.num_outs:
+            lv.append(((lv[-1][0] - 1) // 2 + 1, (lv[-1][1] - 1) // 2 + 1))
+        for (a, b_) in lv:
+            total += self.rpn_head.conv.macs(a, b_) + self.rpn_head.out.macs(a, b_)
+        r = num_rois if num_rois is not None else self.rpn_head.max_per_img
+        for m in self.roi_head.modules():
+            total += r * m.cout * m.cin
+        return total

@@ -1,0 +1,48 @@
+"""Image sharding across the GPUs of a node and the single collective of the inference path.
+
+The reference has no inference collective (only training all-reduce through MindSpore
+wrappers; its dataset sharding `num_shards/shard_id` -- centernet/src/dataset.py:411-418 -- is the same
+contiguous partition used here).  Contract: global batch B -> rank r takes images
+[r*B/N, (r+1)*B/N); each rank runs the full path to padded detections; ONE all_gather per batch of a
+fixed-shape fp32 tensor [B_local, max_det+1, 7] = rows (x1,y1,x2,y2,score,label,valid) + one count row.
+Payload is a few hundred KB per rank: latency-bound on xGMI, so it is a single fused call, never
+per-image gathers.  torch.distributed backend "nccl" is RCCL on ROCm; "gloo" works for CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(global_batch, rank, world):
+    """Contiguous image range of `rank` (gathered order == input order)."""
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} not divisible by world size {world}")
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+def pack_for_gather(dets, count):
+    """dets [B,max_det,6], count [B] -> [B, max_det+1, 7]."""
+    B, M, _ = dets.shape
+    buf = torch.zeros((B, M + 1, 7), dtype=torch.float32, device=dets.device)
+    buf[:, :M, :6] = dets
+    valid = torch.arange(M, device=dets.device).view(1, M) < count.view(B, 1)
+    buf[:, :M, 6] = valid.to(torch.float32)
+    buf[:, M, 0] = count.to(torch.float32)
+    return buf
+
+
+def unpack_gathered(buf):
+    """[B_total, max_det+1, 7] -> (dets [B_total,max_det,6], count [B_total] int32)."""
+    M = buf.shape[1] - 1
+    return buf[:, :M, :6].contiguous(), buf[:, M, 0].to(torch.int32)
+
+
+def gather_detections(dets, count, group=None):
+    """All ranks end up with the detections of the whole global batch, in input order."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return dets, count
+    world = dist.get_world_size(group)
+    buf = pack_for_gather(dets, count)
+    out = torch.empty((world * buf.shape[0],) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    return unpack_gathered(out)

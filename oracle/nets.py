@@ -1,0 +1,214 @@
+"""torch-CPU fp32 ORACLE for the conv graphs and the two-stage pipeline -- TEST INFRASTRUCTURE ONLY.
+
+Conv/BN/ReLU = torch.nn.functional.conv2d on the fp32 parameters held by the product modules in the
+REFERENCE layout (weight [Cout,Cin,kh,kw], BN folded exactly as SURVEY 8(c) states:
+w' = w*gamma/sqrt(var+eps), b' = beta - mean*gamma/sqrt(var+eps)).  Graph structure follows
+minddet/models/centernet/src/resnet.py:109-252 (BasicBlock / Bottleneck / ResNet; zero-pad +
+MaxPool2d(3,2)).  FPN / RPN / RoI head have no reference counterpart ("parity unpinned"): they
+restate the public definitions, mirroring minddet_amd/graphs.py op for op.
+
+`quant=True` rounds weights and every layer output to bf16 (what the device stores), which isolates
+kernel arithmetic error from bf16 storage error in the parity tests; `quant=False` is the plain fp32
+baseline that bench.py times as cpu_baseline.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import np_ops
+import oracle
+
+
+def _q(t, quant):
+    return t.to(torch.bfloat16).float() if quant else t
+
+
+def fold(m):
+    w = m.weight.float()
+    if m.bn is not None:
+        gamma, beta, mean, var, eps = m.bn
+        scale = gamma / torch.sqrt(var + eps)
+        w = w * scale.view(-1, 1, 1, 1)
+        b = beta - mean * scale
+        if m.bias is not None:
+            b = b + m.bias * scale
+    else:
+        b = m.bias.float() if m.bias is not None else torch.zeros(w.shape[0])
+    return w, b
+
+
+def conv_module(m, x, residual=None, quant=False):
+    """x NCHW fp32. Mirrors md_conv2d's epilogue order: bias -> (bf16 round) -> +residual -> ReLU -> round."""
+    w, b = fold(m)
+    y = F.conv2d(x, _q(w, quant), b, stride=m.stride, padding=m.pad)
+    if residual is not None:
+        y = _q(y, quant) + residual
+    if m.relu:
+        y = torch.relu(y)
+    return _q(y, quant)
+
+
+def resnet_forward(bb, x, quant=False):
+    x = conv_module(bb.conv1, x, quant=quant)
+    x = F.max_pool2d(F.pad(x, (1, 1, 1, 1), value=0.0), 3, 2)  # resnet.py:199-204
+    outs = []
+    for st in bb.stages:
+        for blk in st:
+            res = conv_module(blk.downsample, x, quant=quant) if blk.downsample is not None else x
+            mods = [m for m in blk.modules() if m is not blk.downsample]
+            out = x
+            for m in mods[:-1]:
+                out = conv_module(m, out, quant=quant)
+            x = conv_module(mods[-1], out, residual=res, quant=quant)
+        outs.append(x)
+    return outs
+
+
+def fpn_forward(neck, feats, quant=False):
+    lats = [conv_module(l, f, quant=quant) for l, f in zip(neck.lateral, feats)]
+    for i in range(len(lats) - 1, 0, -1):
+        up = F.interpolate(lats[i], size=lats[i - 1].shape[-2:], mode="nearest")
+        lats[i - 1] = _q(lats[i - 1] + up, quant)
+    outs = [conv_module(o, l, quant=quant) for o, l in zip(neck.output, lats)]
+    while len(outs) < neck.num_outs:
+        outs.append(F.max_pool2d(outs[-1], 1, 2))
+    return outs
+
+
+def rpn_heads(rpn, feats, quant=False):
+    return [conv_module(rpn.out, conv_module(rpn.conv, f, quant=quant), quant=quant) for f in feats]
+
+
+# ----------------------------------------------------------------------------- post-conv pipeline (numpy)
+def rpn_level_select(head_nhwc, A, k):
+    """head_nhwc [H,W,Cp] float; logits = channels [0,A) flattened (loc, a). Returns (idx, cnt)."""
+    logits = head_nhwc[..., :A].reshape(-1).astype(np.float32)
+    v, i = np_ops.topk_desc_stable(logits, k)
+    return i, len(i)
+
+
+def rpn_level_decode(head_nhwc, anchors, idx, A, img_hw):
+    h = head_nhwc.reshape(-1, head_nhwc.shape[-1]).astype(np.float32)
+    loc, a = idx // A, idx % A
+    logit = h[loc, a]
+    d = np.stack([h[loc, A + a * 4 + j] for j in range(4)], -1)
+    boxes = np_ops.delta2bbox(anchors[idx], d, max_shape=img_hw)
+    score = (1.0 / (1.0 + np.exp(-logit.astype(np.float64)))).astype(np.float32)
+    return boxes, score
+
+
+def proposals_from_lists(boxes, scores, counts, nms_thr, post):
+    """boxes [L,B,k,4], scores [L,B,k], counts [L,B] (device outputs or oracle's own).  Returns per image
+    (keep masks [L,B,k], merged order indices, rois [B*post,5], cnt [B])."""
+    L, B, k = scores.shape
+    keep = np.zeros((L, B, k), np.uint8)
+    for l in range(L):
+        for b in range(B):
+            c = int(counts[l, b])
+            keep[l, b, :c] = oracle.nms_aligned(boxes[l, b, :c], nms_thr, 0.0, 2)
+    mboxes = boxes.transpose(1, 0, 2, 3).reshape(B, L * k, 4)
+    mscores = np.where(keep.astype(bool), scores, -np.inf).transpose(1, 0, 2).reshape(B, L * k)
+    rois = np.zeros((B * post, 5), np.float32)
+    cnt = np.zeros(B, np.int32)
+    topi = np.zeros((B, post), np.int32)
+    for b in range(B):
+        n_valid = int(np.isfinite(mscores[b]).sum())
+        v, i = np_ops.topk_desc_stable(mscores[b], post)
+        m = min(post, n_valid)
+        cnt[b] = m
+        topi[b, :m] = i[:m]
+        rois[b * post:(b + 1) * post, 0] = b
+        rois[b * post:b * post + m, 1:] = mboxes[b, i[:m]]
+    return keep, topi, rois, cnt
+
+
+def softmax_np(x):
+    x = x.astype(np.float32)
+    m = x.max(-1, keepdims=True)
+    e = np.exp(x - m)
+    return e / e.sum(-1, keepdims=True)
+
+
+def rcnn_candidates(cls_reg, roi_cnt, nc, score_thr, post):
+    R = cls_reg.shape[0]
+    B = len(roi_cnt)
+    p = softmax_np(cls_reg[:, :nc + 1])[:, :nc]
+    valid = (np.arange(R) % post) < np.repeat(roi_cnt, post)
+    cand = np.where((p > np.float32(score_thr)) & valid[:, None], p, -np.inf).astype(np.float32)
+    return cand.reshape(B, post * nc)
+
+
+def rcnn_finish(cand, cls_reg, rois, nc, reg_offset, img_hw, npre, nms_thr, max_det, post):
+    """From candidate scores (device's or oracle's) to packed detections."""
+    B = cand.shape[0]
+    dets = np.zeros((B, max_det, 6), np.float32)
+    count = np.zeros(B, np.int32)
+    sel = []
+    for b in range(B):
+        n_valid = int(np.isfinite(cand[b]).sum())
+        v, i = np_ops.topk_desc_stable(np.where(np.isfinite(cand[b]), cand[b], -np.inf), npre)
+        m = min(npre, n_valid)
+        v, i = v[:m], i[:m]
+        j, c = i // nc, i % nc
+        r = b * post + j
+        d = np.stack([cls_reg[r, reg_offset + c * 4 + t] for t in range(4)], -1).astype(np.float32)
+        boxes = np_ops.delta2bbox(rois[r, 1:], d, stds=(0.1, 0.1, 0.2, 0.2), max_shape=img_hw) if m else np.zeros((0, 4), np.float32)
+        keep = oracle.nms_aligned(boxes, nms_thr, 0.0, 2, groups=c.astype(np.int32)).astype(bool) if m else np.zeros(0, bool)
+        kidx = np.nonzero(keep)[0][:max_det]
+        n = len(kidx)
+        dets[b, :n, :4] = boxes[kidx]
+        dets[b, :n, 4] = v[kidx]
+        dets[b, :n, 5] = c[kidx]
+        count[b] = n
+        sel.append(dict(idx=i, scores=v, boxes=boxes, labels=c, keep=keep))
+    return dets, count, sel
+
+
+def faster_rcnn_forward(model, images_nhwc, quant=False):
+    """Whole two-stage inference on the CPU. images_nhwc [B,H,W,>=3] float tensor. Returns (dets, count)."""
+    x = images_nhwc[..., :3].permute(0, 3, 1, 2).float().contiguous()
+    B, _, H, W = x.shape
+    feats = fpn_forward(model.neck, resnet_forward(model.backbone, x, quant), quant)
+    rpn, roi = model.rpn_head, model.roi_head
+    heads = rpn_heads(rpn, feats, quant)
+    sizes = [(f.shape[2], f.shape[3]) for f in feats]
+    anchors = np_ops.fpn_anchors(sizes, rpn.strides, rpn.scale, rpn.ratios)
+    L, k, A = len(feats), rpn.nms_pre, rpn.A
+    boxes = np.zeros((L, B, k, 4), np.float32)
+    scores = np.full((L, B, k), -np.inf, np.float32)
+    counts = np.zeros((L, B), np.int32)
+    o = 0
+    for l, hd in enumerate(heads):
+        n = sizes[l][0] * sizes[l][1] * A
+        h = hd.permute(0, 2, 3, 1).numpy()
+        for b in range(B):
+            idx, c = rpn_level_select(h[b], A, k)
+            bx, sc = rpn_level_decode(h[b], anchors[o:o + n], idx, A, (H, W))
+            boxes[l, b, :c], scores[l, b, :c], counts[l, b] = bx, sc, c
+        o += n
+    _, _, rois, cnt = proposals_from_lists(boxes, scores, counts, rpn.nms_thr, rpn.max_per_img)
+    post = rpn.max_per_img
+    R = rois.shape[0]
+    pooled = np.zeros((R, roi.P, roi.P, roi.C), np.float32)
+    lv = np_ops.fpn_level(rois[:, 1:])
+    fnp = [f.numpy() for f in feats[:len(roi.strides)]]
+    lvl_of = np.clip(lv - 2, 0, len(fnp) - 1)
+    for b in range(B):
+        for lvl in range(len(fnp)):
+            sel = np.nonzero((rois[:, 0] == b) & (lvl_of == lvl))[0]
+            if len(sel):
+                pooled[sel] = np_ops.roi_align_fast(fnp[lvl][b], rois[sel, 1:], roi.P, 1.0 / roi.strides[lvl],
+                                                    roi.sampling, True).transpose(0, 2, 3, 1)
+    x2 = torch.from_numpy(pooled.reshape(R, -1))
+    x2 = _q(x2, quant)
+    for m in (roi.fc1, roi.fc2, roi.fc_out):
+        w, b = fold(m)
+        x2 = x2 @ _q(w, quant).view(w.shape[0], -1).t() + b
+        if m.relu:
+            x2 = torch.relu(x2)
+        x2 = _q(x2, quant)
+    cls_reg = x2.numpy()
+    cand = rcnn_candidates(cls_reg, cnt, roi.nc, roi.score_thr, post)
+    dets, count, _ = rcnn_finish(cand, cls_reg, rois, roi.nc, roi.reg_offset, (H, W), roi.nms_pre, roi.nms_thr,
+                                 roi.max_per_img, post)
+    return dets, count

@@ -1,0 +1,150 @@
+"""-m gpu: the two-stage path stage by stage against the CPU oracle on the tiny config (sizes the
+oracle finishes in seconds), plus structural properties at the BASELINE size.
+
+Conv stacks: fp tolerance (bf16 storage on both sides; rtol/atol 3e-2 of rms after ~10 layers).
+Everything index-like downstream (top-k indices, NMS keep masks, RoI order, packed labels) is checked
+BIT-EXACT by feeding the oracle the device tensors at the stage boundary (heads, boxes, scores, cand),
+so a fp difference upstream cannot hide or fake an index mismatch."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets, np_ops
+from tests.conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs MI355X")]
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from minddet.models import Config, build_detector
+
+    cfg = Config.fromfile("configs/faster_rcnn/faster_rcnn_tiny.py")
+    m = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(DEV)
+    g = torch.Generator().manual_seed(0)
+    x = torch.zeros((2, 128, 192, 8))
+    x[..., :3] = torch.randn((2, 128, 192, 3), generator=g)
+    xb = x.to(torch.bfloat16)
+    dets, count, aux = m.forward(xb.to(DEV), return_aux=True)
+    torch.cuda.synchronize()
+    return m, xb, dets, count, aux
+
+
+def test_backbone_fpn_features_vs_torch_fp32(tiny):
+    m, xb, _, _, aux = tiny
+    x = xb[..., :3].float().permute(0, 3, 1, 2).contiguous()
+    ref = nets.fpn_forward(m.neck, nets.resnet_forward(m.backbone, x, quant=True), quant=True)
+    for f_dev, f_ref in zip(aux["feats"], ref):
+        got = f_dev.float().cpu().permute(0, 3, 1, 2)
+        assert got.shape == f_ref.shape
+        rms = f_ref.pow(2).mean().sqrt().item()
+        err = (got - f_ref).abs().max().item()
+        assert err <= 3e-2 * max(rms, 1e-3) + 3e-2 * f_ref.abs().max().item() * 0.1, (err, rms)
+
+
+def test_rpn_stage_indices_exact(tiny):
+    m, xb, _, _, aux = tiny
+    rpn = m.rpn_head
+    H, W = xb.shape[1], xb.shape[2]
+    heads = [h.float().cpu().numpy() for h in aux["rpn"]["heads"]]
+    sizes = [(h.shape[1], h.shape[2]) for h in heads]
+    anchors = np_ops.fpn_anchors(sizes, rpn.strides, rpn.scale, rpn.ratios)
+    boxes_d = aux["rpn"]["boxes"].cpu().numpy()
+    scores_d = aux["rpn"]["scores"].cpu().numpy()
+    counts_d = aux["rpn"]["counts"].cpu().numpy()
+    L, B, k = scores_d.shape
+    o = 0
+    for l, hd in enumerate(heads):
+        n = sizes[l][0] * sizes[l][1] * rpn.A
+        for b in range(B):
+            idx, c = nets.rpn_level_select(hd[b], rpn.A, k)
+            assert counts_d[l, b] == c == min(k, n)
+            bx, sc = nets.rpn_level_decode(hd[b], anchors[o:o + n], idx, rpn.A, (H, W))
+            np.testing.assert_allclose(boxes_d[l, b, :c], bx, rtol=1e-5, atol=2e-3)   # => same anchors selected
+            np.testing.assert_allclose(scores_d[l, b, :c], sc, rtol=1e-5, atol=1e-6)
+            assert (boxes_d[l, b, c:] == 0).all()
+        o += n
+    # NMS + merge + per-image top-k from the DEVICE boxes/scores: exact
+    keep_o, topi_o, rois_o, cnt_o = nets.proposals_from_lists(boxes_d, scores_d, counts_d, rpn.nms_thr, rpn.max_per_img)
+    np.testing.assert_array_equal(aux["rpn"]["keep"].cpu().numpy().reshape(L, B, k), keep_o)
+    np.testing.assert_array_equal(aux["roi_cnt"].cpu().numpy(), cnt_o)
+    np.testing.assert_array_equal(aux["rois"].cpu().numpy(), rois_o)
+
+
+def test_roi_stage(tiny):
+    m, xb, dets, count, aux = tiny
+    roi, post = m.roi_head, m.rpn_head.max_per_img
+    H, W = xb.shape[1], xb.shape[2]
+    rois = aux["rois"].cpu().numpy()
+    cnt = aux["roi_cnt"].cpu().numpy()
+    feats = [f.float().cpu().numpy().transpose(0, 3, 1, 2) for f in aux["feats"][:4]]
+    pooled = aux["roi"]["pooled"].float().cpu().numpy()
+    lv = np.clip(np_ops.fpn_level(rois[:, 1:]) - 2, 0, 3)
+    checked = 0
+    for r in range(0, rois.shape[0], 7):
+        if (r % post) >= cnt[r // post]:
+            continue
+        ref = np_ops.roi_align(feats[lv[r]][int(rois[r, 0])], rois[r:r + 1, 1:], roi.P, 1.0 / roi.strides[lv[r]], 2, True)[0]
+        if np.abs(pooled[r] - ref.transpose(1, 2, 0)).max() <= 1e-2 * (1 + np.abs(ref).max()):
+            checked += 1
+    assert checked >= 0.9 * len([r for r in range(0, rois.shape[0], 7) if (r % post) < cnt[r // post]])
+    # FC stack on the device's pooled features vs fp32 torch (bf16-rounded weights)
+    x2 = torch.from_numpy(pooled.reshape(rois.shape[0], -1))
+    for mod in (roi.fc1, roi.fc2, roi.fc_out):
+        w, b = nets.fold(mod)
+        x2 = x2 @ w.to(torch.bfloat16).float().view(w.shape[0], -1).t() + b
+        if mod.relu:
+            x2 = torch.relu(x2)
+        x2 = x2.to(torch.bfloat16).float()
+    cls_reg_d = aux["roi"]["cls_reg"].float().cpu()
+    n_out = roi.reg_offset + 4 * roi.nc
+    err = (cls_reg_d[:, :n_out] - x2[:, :n_out]).abs().max().item()
+    assert err <= 3e-2 * (1 + x2.abs().max().item()), err
+    # candidate scores from the DEVICE logits (softmax fp tolerance), then everything after from the DEVICE cand: exact
+    cr = cls_reg_d.numpy()
+    cand_o = nets.rcnn_candidates(cr, cnt, roi.nc, roi.score_thr, post)
+    cand_d = aux["roi"]["cand"].cpu().numpy()
+    cand_d = np.where(cand_d < -1e30, -np.inf, cand_d)
+    both = np.isfinite(cand_o) & np.isfinite(cand_d)
+    assert (np.isfinite(cand_o) != np.isfinite(cand_d)).mean() < 1e-3  # threshold flips at 1 ulp only
+    np.testing.assert_allclose(cand_d[both], cand_o[both], rtol=2e-6, atol=1e-7)
+    dets_o, count_o, sel = nets.rcnn_finish(cand_d, cr, rois, roi.nc, roi.reg_offset, (H, W), roi.nms_pre, roi.nms_thr,
+                                            roi.max_per_img, post)
+    np.testing.assert_array_equal(count.cpu().numpy(), count_o)
+    d = dets.cpu().numpy()
+    np.testing.assert_array_equal(d[..., 5], dets_o[..., 5])                  # labels exact
+    np.testing.assert_array_equal(d[..., 4], dets_o[..., 4])                  # scores are the device cand values
+    np.testing.assert_allclose(d[..., :4], dets_o[..., :4], rtol=1e-5, atol=2e-3)
+    for b in range(len(sel)):
+        m_ = len(sel[b]["idx"])
+        np.testing.assert_array_equal(aux["roi"]["sel_idx"].cpu().numpy()[b, :m_], sel[b]["idx"])
+        np.testing.assert_array_equal(aux["roi"]["keep"].cpu().numpy()[b, :m_].astype(bool), sel[b]["keep"])
+    assert count_o.sum() > 0  # the test actually exercises the class-wise NMS
+
+
+def test_full_size_structural_properties():
+    """BASELINE size (R50-FPN, 800x1344, batch 2): shapes, padding, ordering, determinism."""
+    from minddet.models import Config, build_detector
+    from minddet_amd.data import synthetic_images
+
+    cfg = Config.fromfile("configs/faster_rcnn/faster_rcnn_r50_fpn.py")
+    m = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(DEV)
+    x = synthetic_images(2, 800, 1344, device=DEV)
+    dets, count, aux = m.forward(x, return_aux=True)
+    dets2, count2 = m.forward(x)
+    torch.cuda.synchronize()
+    assert [tuple(f.shape[1:3]) for f in aux["feats"]] == [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    assert dets.shape == (2, 100, 6) and aux["rois"].shape == (2000, 5)
+    assert torch.equal(dets, dets2) and torch.equal(count, count2)              # deterministic
+    d, c = dets.cpu().numpy(), count.cpu().numpy()
+    for b in range(2):
+        n = c[b]
+        assert (np.diff(d[b, :n, 4]) <= 0).all() and (d[b, n:] == 0).all()
+        assert (d[b, :n, 0] >= 0).all() and (d[b, :n, 2] <= 1344).all() and (d[b, :n, 3] <= 800).all()
+    # idempotence of the per-level NMS at full size: survivors re-run through NMS all survive
+    from minddet_amd import det_ops
+    boxes, keep = aux["rpn"]["boxes"][0, 0], aux["rpn"]["keep"].view(5, 2, -1)[0, 0].bool()
+    kept = boxes[keep].contiguous()
+    mask2, _, num2 = det_ops.nms_aligned(kept, 0.7, mode=2)
+    assert int(num2[0]) == kept.shape[0] and bool(mask2.all())
