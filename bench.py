@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "faster_rcnn", "faster_rcnn_r50_fpn.py"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-convs", default=None, help="write per-launch conv timings (json) to this path")
     args = ap.parse_args()
 
     import torch
@@ -115,11 +116,27 @@ def main():
                     "conv_ms_per_step": round(tot_ms / max(args.steps, 1), 3),
                     "algorithmic_gflop_per_step": round(tot_fl / max(args.steps, 1) / 1e9, 1)}
 
+    if args.dump_convs and rank == 0 and records:
+        per = {}
+        for e0, e1, fl, xs, cout, k in records:
+            key = f"{xs}->{cout} k{k}"
+            d = per.setdefault(key, [0.0, 0.0, 0])
+            d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += 1
+        rows = [{"layer": k_, "ms_per_step": v[0] / args.steps, "tflops": v[1] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0,
+                 "launches_per_step": v[2] // args.steps} for k_, v in per.items()]
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        with open(args.dump_convs, "w") as f:
+            json.dump(rows, f, indent=1)
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import nets
 
-        torch.set_num_threads(os.cpu_count() or 1)
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or 1
+        torch.set_num_threads(max(1, min(ncpu, 16)))  # the GPU box's CPU share for one GPU is 16 cores
         x1 = images[:1].float().cpu()
         nets.faster_rcnn_forward(model, x1[:, :256, :256], quant=False)  # warm-up on a crop
         tc = time.perf_counter()

@@ -43,7 +43,7 @@ struct ConvArgs {
     int Kreal;    // kh*kw*Cin
     int M;        // N*Ho*Wo
     int cpt;      // chunks (8 ch) per tap = Cin/8
-    int n_ptiles, n_ctiles;
+    int n_ptiles, n_ctiles, pt_per_xcd;
 };
 
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((unsigned)v << 16); }
@@ -61,7 +61,7 @@ constexpr int ROWB = BK * 2;  // bytes per LDS tile row
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <int WC, int WP, int FC, int FP>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
     constexpr int A_ROWS = CT / 32, B_ROWS = PT / 32;  // 16-B chunks per thread per tile
     constexpr int TILE_BYTES = (CT + PT) * ROWB;
@@ -70,8 +70,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave / WP, wp = wave % WP;
-    // cout tile varies fastest: consecutive workgroups share the activation tile (L2 reuse)
-    const int ct = blockIdx.x % a.n_ctiles, pt = blockIdx.x / a.n_ctiles;
+    // XCD-aware tile map (workgroups are dealt round-robin over the 8 XCDs, each with a private L2):
+    // every XCD owns a CONTIGUOUS range of pixel tiles, and inside it the cout tile varies fastest, so the
+    // workgroups that share an activation tile (and the 3x3 halo rows of its neighbours) hit the same L2.
+    // Placement only affects speed: any dispatch order computes the same tiles.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ct = slot % a.n_ctiles, pt = xcd * a.pt_per_xcd + slot / a.n_ctiles;
+    if (pt >= a.n_ptiles) return;
     const int cout0 = ct * CT, pix0 = pt * PT;
 
     const int chunk = tid & 7, row0 = tid >> 3;  // this thread stages rows row0 + 32*i, 16-B chunk `chunk`
@@ -176,7 +181,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: bias (+ReLU when no residual) -> bf16x4 -> LDS [pixel][cout] image
+    // ---- epilogue.  Residual rows are fetched first so that their HBM latency overlaps the LDS transpose.
+    constexpr int CPP = CT / 8;                 // 16-B chunks per pixel row of the tile
+    constexpr int EP_ITERS = PT * CPP / 256;    // chunks per thread
+    u32x4 rres[EP_ITERS];
+    if (a.res) {
+#pragma unroll
+        for (int it = 0; it < EP_ITERS; ++it) {
+            const int e = tid + it * 256;
+            const int p_local = e / CPP, cc = e % CPP;
+            const int m = pix0 + p_local, c = cout0 + cc * 8;
+            rres[it] = (u32x4){0u, 0u, 0u, 0u};
+            if (m < a.M && c < a.Cout) rres[it] = *reinterpret_cast<const u32x4 *>(a.res + (size_t)m * a.Cout + c);
+        }
+    }
+    // bias (+ReLU when no residual) -> bf16x4 -> LDS [pixel][cout] image
     char *E = smem;
 #pragma unroll
     for (int i = 0; i < FC; ++i) {
@@ -201,15 +220,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
     __syncthreads();
     // ---- coalesced NHWC store: 16 B (8 couts) per lane, CT/8 lanes per pixel
-    constexpr int CPP = CT / 8;  // chunks per pixel row
-    for (int e = tid; e < PT * CPP; e += 256) {
+#pragma unroll
+    for (int it = 0; it < EP_ITERS; ++it) {
+        const int e = tid + it * 256;
         const int p_local = e / CPP, cc = e % CPP;
         const int m = pix0 + p_local, c = cout0 + cc * 8;
         if (m >= a.M || c >= a.Cout) continue;
         u32x4 v = *reinterpret_cast<const u32x4 *>(E + p_local * EP_STRIDE + cc * 16);
         const size_t off = (size_t)m * a.Cout + c;
         if (a.res) {
-            const u32x4 rv = *reinterpret_cast<const u32x4 *>(a.res + off);
+            const u32x4 rv = rres[it];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float lo = bf2f((uint16_t)(v[k] & 0xffff)) + bf2f((uint16_t)(rv[k] & 0xffff));
@@ -227,10 +247,14 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
     a.n_ctiles = (a.Cout + CT - 1) / CT;
     a.n_ptiles = (a.M + PT - 1) / PT;
-    constexpr int tile_bytes = (CT + PT) * ROWB * 2;
+    // one staging buffer is enough when the whole K fits one tile (1x1 convs on 64 channels): more
+    // workgroups per CU for the HBM-bound layers
+    const int nbuf = a.Kpad / BK > 1 ? 2 : 1;
+    const int tile_bytes = (CT + PT) * ROWB * nbuf;
     constexpr int ep_bytes = PT * (CT * 2 + 16);
-    constexpr int lds = tile_bytes > ep_bytes ? tile_bytes : ep_bytes;
-    const long long blocks = (long long)a.n_ctiles * a.n_ptiles;
+    const int lds = tile_bytes > ep_bytes ? tile_bytes : ep_bytes;
+    a.pt_per_xcd = (a.n_ptiles + 7) / 8;
+    const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
     auto k = conv_igemm_kernel<WC, WP, FC, FP>;
     if (lds > 64 * 1024) {

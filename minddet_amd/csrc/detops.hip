@@ -175,6 +175,25 @@ __device__ __forceinline__ float funord(unsigned o) {
 constexpr int TOPK_THREADS = 1024;
 constexpr int TOPK_MAXK = 4096;
 
+// Histogram increment with wave-level aggregation.  Detector scores are heavily concentrated (bf16
+// logits: a handful of distinct top bytes), so a plain LDS atomic per lane serialises 64-deep on one
+// address.  Lanes that share the leader's bucket are counted with one ballot and added once; after a
+// few rounds the stragglers (spread-out data) fall back to per-lane atomics.
+__device__ __forceinline__ void hist_add_aggregated(unsigned *hist, bool active, unsigned bucket) {
+#pragma unroll 1
+    for (int round = 0; round < 4; ++round) {
+        const unsigned long long act = __ballot(active);
+        if (act == 0ull) return;
+        const int leader = __ffsll((long long)act) - 1;
+        const unsigned b = __builtin_amdgcn_readlane(bucket, leader);
+        const bool same = active && bucket == b;
+        const unsigned long long m = __ballot(same);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b], (unsigned)__popcll(m));
+        active = active && !same;
+    }
+    if (active) atomicAdd(&hist[bucket], 1u);
+}
+
 // One workgroup per segment.  Selects the k largest scores strictly greater than min_score
 // (ties resolved towards the LOWER index), returns them sorted descending (stable).
 // seg_off[L+1] (int32, elements).  out_val/out_idx are [L,k]; padded with (-FLT_MAX, 0); out_cnt[L].
@@ -213,9 +232,11 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_segmented_kernel(const floa
             const int shift = 24 - 8 * pass;
             for (int i = tid; i < 256; i += TOPK_THREADS) hist[i] = 0;
             __syncthreads();
-            for (int i = tid; i < n; i += TOPK_THREADS) {
-                const unsigned u = ford(sc[i]);
-                if (u > omin && (u & maskbits) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+            for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {   // uniform trip count: ballots inside
+                const int i = i0 + tid;
+                const unsigned u = i < n ? ford(sc[i]) : 0u;
+                const bool act = i < n && u > omin && (u & maskbits) == prefix;
+                hist_add_aggregated(hist, act, (u >> shift) & 255u);
             }
             __syncthreads();
             if (tid == 0) {
