@@ -113,6 +113,8 @@ int md_circle_nms(MD_AOT_ARGS);
 typedef struct md_conv2d_attrs {
     int32_t kh, kw, stride, pad; /* square stride / symmetric zero padding */
     int32_t relu;                /* 1: ReLU after bias (+ residual) */
+    int32_t variant;             /* 0 = auto (default). Tile/staging variant for A/B measurements:
+                                    1 register-staged 128x128, 2 LDS-DMA 128x128, 3 LDS-DMA 256x256 */
 } md_conv2d_attrs;
 /* Replaces Conv2d -> BatchNorm2d(eval) -> [+ residual] -> ReLU of the reference graphs
  * (centernet/src/resnet.py:109-178,181-252; centerpoint/det3d_ms/models/necks/rpn.py:9-154).
@@ -199,9 +201,12 @@ int md_delta2bbox(MD_AOT_ARGS);
 typedef struct md_topk_attrs {
     int32_t k;        /* <= 4096 */
     float min_score;  /* only scores > min_score are selectable; -FLT_MAX to disable */
+    int32_t max_segment; /* upper bound of the segment lengths if the caller knows it (seg_off lives on the
+                            device); > 32768 switches to the multi-workgroup select. 0 = unknown */
 } md_topk_attrs;
 /* in scores[T] f32, seg_off[L+1] i32 ; out values[L,k] f32 (padded -FLT_MAX), indices[L,k] i32
- * (relative to the segment, padded 0), count[L] i32. */
+ * (relative to the segment, padded 0), count[L] i32 ; optional workspace
+ * (L*(2048*4+4) rounded up to 256, + L*8192*8 bytes) for the multi-workgroup path. */
 int md_topk_segmented(MD_AOT_ARGS);
 
 /* ------------------------------------------------------------------------------------------

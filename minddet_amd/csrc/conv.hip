@@ -44,6 +44,7 @@ struct ConvArgs {
     int M;        // N*Ho*Wo
     int cpt;      // chunks (8 ch) per tap = Cin/8
     int n_ptiles, n_ctiles, pt_per_xcd;
+    unsigned x_bytes, w_bytes;  // buffer sizes for the LDS-DMA descriptors (< 2 GiB each)
 };
 
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((unsigned)v << 16); }
@@ -60,12 +61,30 @@ constexpr int ROWB = BK * 2;  // bytes per LDS tile row
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int WC, int WP, int FC, int FP>
-__global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
+// 16 zero bytes: the source of every out-of-image / past-K chunk when staging with LDS-DMA
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+// Template: NT threads (256 = 4 waves, 512 = 8 waves), waves arranged WC (cout) x WP (pixels), each wave
+// owning FC x FP accumulator tiles of 32x32.
+// MODE 0: register-staged tiles (global_load -> VGPR -> ds_write), 64-bit addressing, any size.
+// MODE 1: LDS-DMA staging (buffer_load_dwordx4 ... lds: no VGPR round trip, hardware range check = free
+//         zero fill of padding taps), generic K walk (any Cin % 8 == 0, e.g. the 7x7 stem on 8 channels).
+// MODE 2: LDS-DMA, Cin % 64 == 0 and <= 32 taps: one K tile never straddles a tap, so the tap walk is
+//         scalar (SALU) and goes into the instruction's soffset; per tile a lane spends 3 VALU per
+//         activation row (tap-validity bit -> select the out-of-range offset) and none on weights.
+// The LDS image of a DMA is lane-linear per wave instruction (8 rows x 128 B), so the XOR swizzle is
+// applied to the per-lane SOURCE chunk and to the fragment reads, never to the destination.
+template <int NT, int WC, int WP, int FC, int FP, int MODE>
+__global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
+    constexpr bool GLDS = MODE != 0;
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
-    constexpr int A_ROWS = CT / 32, B_ROWS = PT / 32;  // 16-B chunks per thread per tile
+    constexpr int RPP = NT / 8;                            // tile rows staged per pass of the workgroup
+    constexpr int A_ROWS = CT / RPP, B_ROWS = PT / RPP;    // 16-B chunks per thread per tile
     constexpr int TILE_BYTES = (CT + PT) * ROWB;
-    constexpr int EP_STRIDE = CT * 2 + 16;  // epilogue image row stride (bytes)
+    constexpr int EP_STRIDE = CT * 2 + 16;                 // epilogue image row stride (bytes)
+    constexpr unsigned OOR = 0x80000000u;                  // byte offset past any buffer (< 2 GiB): reads as 0
+    static_assert(WC * WP * 64 == NT, "wave grid must cover the workgroup");
+    static_assert(CT % RPP == 0 && PT % RPP == 0, "tile rows must be a multiple of the staging pass");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -79,53 +98,41 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
     if (pt >= a.n_ptiles) return;
     const int cout0 = ct * CT, pix0 = pt * PT;
 
-    const int chunk = tid & 7, row0 = tid >> 3;  // this thread stages rows row0 + 32*i, 16-B chunk `chunk`
+    // this thread stages rows row0 + RPP*i; physical 16-B slot (tid & 7) of the row holds LOGICAL k-chunk
+    // `chunk` (the swizzle term (row>>1)&7 is the same for all of a thread's rows because RPP % 16 == 0)
+    const int row0 = tid >> 3;
+    const int chunk = GLDS ? ((tid & 7) ^ ((row0 >> 1) & 7)) : (tid & 7);
+    const int n_taps = a.kh * a.kw;
+    const int nk = a.Kpad / BK;
 
     // per-thread pixel rows of the B (activation) tile
-    int p_hw0[B_ROWS];   // packed (hi0 << 16) | (wi0 & 0xffff), hi0/wi0 = top-left input coord of the window
-    int p_base[B_ROWS];  // n*H*W (pixel index), or -1 if the row is past M
+    int p_hw0[B_ROWS];        // packed (hi0 << 16) | (wi0 & 0xffff): top-left input coord of the window
+    int p_base[B_ROWS];       // MODE 0: n*H*W (pixel index) or -1 past M.  MODE 1/2: byte offset of (n,hi0,wi0,chunk)
+    unsigned p_taps[B_ROWS];  // MODE 2: bit t set <=> tap t of this row is inside the image (0 past M)
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) {
-        const int m = pix0 + row0 + 32 * i;
+        const int m = pix0 + row0 + RPP * i;
+        p_hw0[i] = 0; p_base[i] = -1; p_taps[i] = 0u;
         if (m < a.M) {
             const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
             const int ho = r / a.Wo, wo = r - ho * a.Wo;
             const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
             p_hw0[i] = (hi0 << 16) | (wi0 & 0xffff);
-            p_base[i] = n * a.H * a.W;
-        } else {
-            p_hw0[i] = 0;
-            p_base[i] = -1;
-        }
+            if constexpr (MODE == 0) p_base[i] = n * a.H * a.W;
+            else p_base[i] = (((n * a.H + hi0) * a.W + wi0) * a.Cin) * 2 + (MODE == 2 ? chunk * 16 : 0);
+            if constexpr (MODE == 2) {
+                unsigned bits = 0u, bit = 1u;
+                for (int dy = 0; dy < a.kh; ++dy)
+                    for (int dx = 0; dx < a.kw; ++dx, bit <<= 1)
+                        if ((unsigned)(hi0 + dy) < (unsigned)a.H && (unsigned)(wi0 + dx) < (unsigned)a.W) bits |= bit;
+                p_taps[i] = bits;
+            }
+        } else if constexpr (MODE != 0) p_hw0[i] = (int)0x80008000;  // hi0 = wi0 = -32768: every tap out of image
     }
-    // K position of this thread's chunk: tap index and channel-chunk within tap, advanced by 8 chunks per tile
+    // generic K walk (MODE 0/1): tap index and channel-chunk of this thread's chunk, advanced 8 chunks per tile
     int q_tap = chunk / a.cpt, q_cc = chunk - q_tap * a.cpt;
     int q_kh = q_tap / a.kw, q_kw = q_tap - q_kh * a.kw;
-    const int n_taps = a.kh * a.kw;
-
-    u32x4 ra[A_ROWS], rb[B_ROWS];
-    const int nk = a.Kpad / BK;
-
-    auto load_tile = [&](int kt) {
-        // weights: plain 2-D, always in bounds (padded at pack time)
-#pragma unroll
-        for (int i = 0; i < A_ROWS; ++i) {
-            const int r = cout0 + row0 + 32 * i;
-            ra[i] = *reinterpret_cast<const u32x4 *>(a.w + (size_t)r * a.Kpad + kt * BK + chunk * 8);
-        }
-        const bool tap_ok = q_tap < n_taps;
-#pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) {
-            const int hi = (p_hw0[i] >> 16) + q_kh, wi = (int)(short)(p_hw0[i] & 0xffff) + q_kw;
-            const bool ok = tap_ok && p_base[i] >= 0 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) {
-                const size_t off = ((size_t)(p_base[i] + hi * a.W + wi)) * a.Cin + q_cc * 8;
-                v = *reinterpret_cast<const u32x4 *>(a.x + off);
-            }
-            rb[i] = v;
-        }
-        // advance this thread's K position by one tile (8 chunks)
+    auto advance_k = [&]() {
         q_cc += 8;
         while (q_cc >= a.cpt) {
             q_cc -= a.cpt;
@@ -133,12 +140,71 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
             if (++q_kw == a.kw) { q_kw = 0; ++q_kh; }
         }
     };
+    // scalar K walk (MODE 2): the whole tile sits in tap s_tap at channel offset s_cc0 (multiples of 8 chunks)
+    int s_tap = 0, s_cc0 = 0, s_kh = 0, s_kw = 0;
+
+    u32x4 ra[GLDS ? 1 : A_ROWS], rb[GLDS ? 1 : B_ROWS];
+    // ---- staging, register path (MODE 0)
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i)
+            ra[GLDS ? 0 : i] = *reinterpret_cast<const u32x4 *>(a.w + (size_t)(cout0 + row0 + RPP * i) * a.Kpad + kt * BK + chunk * 8);
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) {
+            const int hi = (p_hw0[i] >> 16) + q_kh, wi = (int)(short)(p_hw0[i] & 0xffff) + q_kw;
+            const bool ok = q_tap < n_taps && p_base[i] >= 0 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = *reinterpret_cast<const u32x4 *>(a.x + ((size_t)(p_base[i] + hi * a.W + wi)) * a.Cin + q_cc * 8);
+            rb[GLDS ? 0 : i] = v;
+        }
+        advance_k();
+    };
     auto store_tile = [&](int buf) {
         char *A = smem + buf * TILE_BYTES, *B = A + CT * ROWB;
 #pragma unroll
-        for (int i = 0; i < A_ROWS; ++i) *reinterpret_cast<u32x4 *>(A + swz(row0 + 32 * i, chunk)) = ra[i];
+        for (int i = 0; i < A_ROWS; ++i) *reinterpret_cast<u32x4 *>(A + swz(row0 + RPP * i, tid & 7)) = ra[GLDS ? 0 : i];
 #pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<u32x4 *>(B + swz(row0 + 32 * i, chunk)) = rb[i];
+        for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<u32x4 *>(B + swz(row0 + RPP * i, tid & 7)) = rb[GLDS ? 0 : i];
+    };
+    // ---- staging, LDS-DMA path: one wave instruction fills 8 rows x 128 B = 1 KiB, destination lane-linear
+    __amdgpu_buffer_rsrc_t rs_w, rs_x;
+    int a_off0 = 0;
+    if constexpr (GLDS) {
+        rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
+        rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+        a_off0 = ((cout0 + row0) * a.Kpad + chunk * 8) * 2;
+    }
+    const int wrow = (tid >> 6) * 8;  // first row of this wave's 8-row group inside a staging pass
+    auto dma_tile = [&](int kt, int buf) {
+        typedef __attribute__((address_space(3))) void lds_void;
+        char *A = smem + buf * TILE_BYTES, *B = A + CT * ROWB;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(A + (wrow + RPP * i) * ROWB), 16,
+                                                     a_off0 + i * (RPP * a.Kpad * 2), kt * (BK * 2), 0, 0);
+        if constexpr (MODE == 2) {
+            const int soff = ((s_kh * a.W + s_kw) * a.Cin + s_cc0 * 8) * 2;
+#pragma unroll
+            for (int i = 0; i < B_ROWS; ++i) {
+                const unsigned voff = ((p_taps[i] >> s_tap) & 1u) ? (unsigned)(p_base[i] + soff) : OOR;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(B + (wrow + RPP * i) * ROWB), 16, (int)voff, 0, 0, 0);
+            }
+            s_cc0 += 8;
+            if (s_cc0 == a.cpt) {
+                s_cc0 = 0; ++s_tap;
+                if (++s_kw == a.kw) { s_kw = 0; ++s_kh; }
+            }
+        } else {
+            const int tapoff = ((q_kh * a.W + q_kw) * a.Cin + q_cc * 8) * 2;
+#pragma unroll
+            for (int i = 0; i < B_ROWS; ++i) {
+                const int hi = (p_hw0[i] >> 16) + q_kh, wi = (int)(short)(p_hw0[i] & 0xffff) + q_kw;
+                const bool ok = q_tap < n_taps && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                const unsigned voff = ok ? (unsigned)(p_base[i] + tapoff) : OOR;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(B + (wrow + RPP * i) * ROWB), 16, (int)voff, 0, 0, 0);
+            }
+            advance_k();
+        }
     };
 
     f32x16 acc[FC][FP];
@@ -149,46 +215,63 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
     const int lr = lane & 31, lh = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const char *A = smem + buf * TILE_BYTES, *B = A + CT * ROWB;
+    // fragment read addresses: the swizzle term is the same for every fragment row of a lane (rows differ by
+    // multiples of 32), so 4 bases per operand (one per k-step) + immediates cover a whole tile
+    int fa_off[BK / 16], fb_off[BK / 16];
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+        fa_off[kk] = swz(wc * FC * 32 + lr, kk * 2 + lh);
+        fb_off[kk] = CT * ROWB + swz(wp * FP * 32 + lr, kk * 2 + lh);
+    }
+    auto compute_tile = [&](int buf) {
+        const char *T = smem + buf * TILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             bf16x8 fa[FC], fb[FP];
 #pragma unroll
-            for (int i = 0; i < FC; ++i) {
-                const int r = (wc * FC + i) * 32 + lr;
-                fa[i] = *reinterpret_cast<const bf16x8 *>(A + swz(r, kk * 2 + lh));
-            }
+            for (int i = 0; i < FC; ++i) fa[i] = *reinterpret_cast<const bf16x8 *>(T + fa_off[kk] + i * 32 * ROWB);
 #pragma unroll
-            for (int j = 0; j < FP; ++j) {
-                const int r = (wp * FP + j) * 32 + lr;
-                fb[j] = *reinterpret_cast<const bf16x8 *>(B + swz(r, kk * 2 + lh));
-            }
+            for (int j = 0; j < FP; ++j) fb[j] = *reinterpret_cast<const bf16x8 *>(T + fb_off[kk] + j * 32 * ROWB);
 #pragma unroll
             for (int i = 0; i < FC; ++i)
 #pragma unroll
                 for (int j = 0; j < FP; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+    };
+
+    if constexpr (GLDS) {
+        dma_tile(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            // tile kt has landed (every wave waits for its own DMAs, the barrier publishes them) and every
+            // wave has finished reading the other buffer in the previous iteration -> safe to refill it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) dma_tile(kt + 1, (kt + 1) & 1);
+            compute_tile(kt & 1);
+        }
         __syncthreads();
+    } else {
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tile(kt + 1);
+            compute_tile(kt & 1);
+            if (kt + 1 < nk) store_tile((kt & 1) ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue.  Residual rows are fetched first so that their HBM latency overlaps the LDS transpose.
     constexpr int CPP = CT / 8;                 // 16-B chunks per pixel row of the tile
-    constexpr int EP_ITERS = PT * CPP / 256;    // chunks per thread
+    constexpr int EP_ITERS = PT * CPP / NT;     // chunks per thread
     u32x4 rres[EP_ITERS];
     if (a.res) {
 #pragma unroll
         for (int it = 0; it < EP_ITERS; ++it) {
-            const int e = tid + it * 256;
+            const int e = tid + it * NT;
             const int p_local = e / CPP, cc = e % CPP;
             const int m = pix0 + p_local, c = cout0 + cc * 8;
             rres[it] = (u32x4){0u, 0u, 0u, 0u};
@@ -222,7 +305,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
     // ---- coalesced NHWC store: 16 B (8 couts) per lane, CT/8 lanes per pixel
 #pragma unroll
     for (int it = 0; it < EP_ITERS; ++it) {
-        const int e = tid + it * 256;
+        const int e = tid + it * NT;
         const int p_local = e / CPP, cc = e % CPP;
         const int m = pix0 + p_local, c = cout0 + cc * 8;
         if (m >= a.M || c >= a.Cout) continue;
@@ -242,7 +325,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
-template <int WC, int WP, int FC, int FP>
+template <int NT, int WC, int WP, int FC, int FP, int MODE>
 static int launch_conv(ConvArgs &a, hipStream_t s) {
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
     a.n_ctiles = (a.Cout + CT - 1) / CT;
@@ -256,12 +339,12 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
     a.pt_per_xcd = (a.n_ptiles + 7) / 8;
     const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
-    auto k = conv_igemm_kernel<WC, WP, FC, FP>;
+    auto k = conv_igemm_kernel<NT, WC, WP, FC, FP, MODE>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return MD_ERR_HIP;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NT), lds, s, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
@@ -308,7 +391,24 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     a.M = (int)M;
     a.cpt = a.Cin / 8;
     hipStream_t s = (hipStream_t)stream;
-    if (ctile == 128) return launch_conv<2, 2, 2, 2>(a, s);
-    if (ctile == 64) return launch_conv<1, 4, 2, 2>(a, s);
-    return launch_conv<1, 4, 1, 2>(a, s);
+    // variant: 0 = auto; 1 = register-staged 128x128; 2 = LDS-DMA 128x128; 3 = LDS-DMA 256(cout)x256(pix), 8 waves
+    int variant = at->variant;
+    const long long x_bytes = (long long)a.N * a.H * a.W * a.Cin * 2, w_bytes = (long long)cout_pad * a.Kpad * 2;
+    const bool dma_ok = x_bytes < 0x7fff0000LL && w_bytes < 0x7fff0000LL;  // 32-bit DMA offsets, out-of-range marker 2^31
+    a.x_bytes = (unsigned)(dma_ok ? x_bytes : 0);
+    a.w_bytes = (unsigned)(dma_ok ? w_bytes : 0);
+    if (!dma_ok) variant = 1;
+    const bool fast = a.Cin % 64 == 0 && a.kh * a.kw <= 32;  // MODE 2 preconditions (then Kpad == Kreal)
+    if (ctile != 128) {
+        if (variant == 1) return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 0>(a, s) : launch_conv<256, 1, 4, 1, 2, 0>(a, s);
+        if (fast) return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 2>(a, s) : launch_conv<256, 1, 4, 1, 2, 2>(a, s);
+        return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 1>(a, s) : launch_conv<256, 1, 4, 1, 2, 1>(a, s);
+    }
+    const bool can256 = cout_pad % 256 == 0;
+    if (variant == 0) variant = 2;  // measured (tools/conv_ab.py, r01): the 128x128 LDS-DMA kernel at 2 workgroups/CU beats
+                                    // the 256x256 8-wave one on every benchmark layer with this one-barrier-per-tile loop
+    if (variant == 3 && !can256) variant = 2;
+    if (variant == 1) return launch_conv<256, 2, 2, 2, 2, 0>(a, s);
+    if (variant == 3) return fast ? launch_conv<512, 2, 4, 4, 2, 2>(a, s) : launch_conv<512, 2, 4, 4, 2, 1>(a, s);
+    return fast ? launch_conv<256, 2, 2, 2, 2, 2>(a, s) : launch_conv<256, 2, 2, 2, 2, 1>(a, s);
 }

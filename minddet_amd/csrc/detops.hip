@@ -180,32 +180,27 @@ constexpr int TOPK_MAXK = 4096;
 // address.  Lanes that share the leader's bucket are counted with one ballot and added once; after a
 // few rounds the stragglers (spread-out data) fall back to per-lane atomics.
 __device__ __forceinline__ void hist_add_aggregated(unsigned *hist, bool active, unsigned bucket) {
-#pragma unroll 1
-    for (int round = 0; round < 4; ++round) {
-        const unsigned long long act = __ballot(active);
-        if (act == 0ull) return;
-        const int leader = __ffsll((long long)act) - 1;
-        const unsigned b = __builtin_amdgcn_readlane(bucket, leader);
-        const bool same = active && bucket == b;
-        const unsigned long long m = __ballot(same);
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b], (unsigned)__popcll(m));
-        active = active && !same;
+    const unsigned long long act = __ballot(active);
+    if (act == 0ull) return;
+    const int leader = __ffsll((long long)act) - 1;
+    const unsigned b = __builtin_amdgcn_readlane(bucket, leader);
+    const unsigned long long same = __ballot(active && bucket == b);
+    if (same == act) {  // every active lane hits one bucket (degenerate digit): one add for the wave
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b], (unsigned)__popcll(act));
+    } else if (active) {
+        atomicAdd(&hist[bucket], 1u);
     }
-    if (active) atomicAdd(&hist[bucket], 1u);
 }
 
 // One workgroup per segment.  Selects the k largest scores strictly greater than min_score
 // (ties resolved towards the LOWER index), returns them sorted descending (stable).
 // seg_off[L+1] (int32, elements).  out_val/out_idx are [L,k]; padded with (-FLT_MAX, 0); out_cnt[L].
-__global__ __launch_bounds__(TOPK_THREADS) void topk_segmented_kernel(const float *__restrict__ scores,
-                                                                      const int *__restrict__ seg_off, int k,
-                                                                      float min_score, float *__restrict__ out_val,
-                                                                      int *__restrict__ out_idx,
-                                                                      int *__restrict__ out_cnt) {
-    __shared__ unsigned long long sel[TOPK_MAXK];
+__device__ void topk_block_select(const float *__restrict__ scores, const int *__restrict__ seg_off, int seg, int k,
+                                  float min_score, float *__restrict__ out_val, int *__restrict__ out_idx,
+                                  int *__restrict__ out_cnt, unsigned long long *sel /* LDS, TOPK_MAXK entries */) {
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_remaining, s_count, s_wave_base[TOPK_THREADS / 64], s_tie_taken;
-    const int seg = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int beg = seg_off[seg], n = seg_off[seg + 1] - beg;
     const float *sc = scores + beg;
     const unsigned omin = ford(min_score);
@@ -314,6 +309,134 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_segmented_kernel(const floa
         int id = 0;
         if (i < kk) {
             const unsigned long long e = sel[i];
+            v = funord(~(unsigned)(e >> 32));
+            id = (int)(unsigned)(e & 0xffffffffu);
+        }
+        out_val[(size_t)seg * k + i] = v;
+        out_idx[(size_t)seg * k + i] = id;
+    }
+    if (tid == 0) out_cnt[seg] = kk;
+}
+
+__global__ __launch_bounds__(TOPK_THREADS) void topk_segmented_kernel(const float *__restrict__ scores,
+                                                                      const int *__restrict__ seg_off, int k,
+                                                                      float min_score, float *__restrict__ out_val,
+                                                                      int *__restrict__ out_idx,
+                                                                      int *__restrict__ out_cnt) {
+    __shared__ unsigned long long sel[TOPK_MAXK];
+    topk_block_select(scores, seg_off, blockIdx.x, k, min_score, out_val, out_idx, out_cnt, sel);
+}
+
+// ---- multi-workgroup path for long segments (RPN level P2: 201 600 scores per image).
+// A: per-chunk LDS histogram of the top 11 ordinal bits -> global histogram per segment.
+// C: every chunk finds the boundary bin b1 (count(bin > b1) < k <= count(bin >= b1)) and appends the
+//    candidates (bin >= b1) as 64-bit keys (~ordinal << 32 | index) to the segment's candidate list.
+// D: one workgroup per segment sorts the (few thousand) candidates in LDS: ascending key order ==
+//    descending score, ascending index -> exact stable top-k.  If the candidate list overflowed (extreme
+//    ties) the segment falls back to the single-workgroup select above.
+constexpr int TK_BINS = 2048;
+constexpr int TK_CHUNK = 8192;
+constexpr int TK_CAP = 8192;
+
+__global__ __launch_bounds__(256) void topk_hist_kernel(const float *__restrict__ scores, const int *__restrict__ seg_off,
+                                                        float min_score, unsigned *__restrict__ ghist) {
+    __shared__ unsigned hist[TK_BINS];
+    const int seg = blockIdx.y, tid = threadIdx.x;
+    const int beg = seg_off[seg], n = seg_off[seg + 1] - beg;
+    const int c0 = blockIdx.x * TK_CHUNK;
+    if (c0 >= n) return;
+    const int c1 = min(n, c0 + TK_CHUNK);
+    for (int i = tid; i < TK_BINS; i += 256) hist[i] = 0;
+    __syncthreads();
+    const unsigned omin = ford(min_score);
+    for (int i = c0 + tid; i < c1; i += 256) {
+        const unsigned u = ford(scores[beg + i]);
+        if (u > omin) atomicAdd(&hist[u >> 21], 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < TK_BINS; i += 256) {
+        const unsigned v = hist[i];
+        if (v) atomicAdd(&ghist[(size_t)seg * TK_BINS + i], v);
+    }
+}
+
+__global__ __launch_bounds__(256) void topk_compact_kernel(const float *__restrict__ scores, const int *__restrict__ seg_off,
+                                                           int k, float min_score, const unsigned *__restrict__ ghist,
+                                                           unsigned *__restrict__ cand_cnt,
+                                                           unsigned long long *__restrict__ cand) {
+    __shared__ unsigned part[256];
+    __shared__ int s_b1;
+    const int seg = blockIdx.y, tid = threadIdx.x;
+    const int beg = seg_off[seg], n = seg_off[seg + 1] - beg;
+    const int c0 = blockIdx.x * TK_CHUNK;
+    if (c0 >= n) return;
+    const int c1 = min(n, c0 + TK_CHUNK);
+    // boundary bin: thread t owns bins [8t, 8t+8); suffix sums from the top
+    const unsigned *gh = ghist + (size_t)seg * TK_BINS;
+    unsigned mine[8], tot = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mine[j] = gh[tid * 8 + j]; tot += mine[j]; }
+    part[tid] = tot;
+    if (tid == 0) s_b1 = 0;
+    __syncthreads();
+    unsigned above = 0;  // count in bins owned by higher threads
+    for (int t = tid + 1; t < 256; ++t) above += part[t];
+    if (above < (unsigned)k && above + tot >= (unsigned)k) {
+        unsigned c = above;
+        int b = tid * 8 + 7;
+        for (int j = 7; j >= 0; --j) {
+            if (c + mine[j] >= (unsigned)k) { b = tid * 8 + j; break; }
+            c += mine[j];
+        }
+        s_b1 = b;
+    }
+    __syncthreads();
+    const unsigned b1 = (unsigned)s_b1;  // stays 0 when fewer than k scores are selectable: everything is a candidate
+    const unsigned omin = ford(min_score);
+    for (int i = c0 + tid; i < c1; i += 256) {
+        const unsigned u = ford(scores[beg + i]);
+        if (u > omin && (u >> 21) >= b1) {
+            const unsigned pos = atomicAdd(&cand_cnt[seg], 1u);
+            if (pos < (unsigned)TK_CAP) cand[(size_t)seg * TK_CAP + pos] = ((unsigned long long)(~u) << 32) | (unsigned)i;
+        }
+    }
+}
+
+__global__ __launch_bounds__(TOPK_THREADS) void topk_final_kernel(const float *__restrict__ scores,
+                                                                  const int *__restrict__ seg_off, int k, float min_score,
+                                                                  const unsigned *__restrict__ cand_cnt,
+                                                                  const unsigned long long *__restrict__ cand,
+                                                                  float *__restrict__ out_val, int *__restrict__ out_idx,
+                                                                  int *__restrict__ out_cnt) {
+    __shared__ unsigned long long keys[TK_CAP];
+    const int seg = blockIdx.x, tid = threadIdx.x;
+    const unsigned nc = cand_cnt[seg];
+    if (nc > (unsigned)TK_CAP) {  // block-uniform
+        topk_block_select(scores, seg_off, seg, k, min_score, out_val, out_idx, out_cnt, keys);
+        return;
+    }
+    int P = 1;
+    while (P < (int)nc) P <<= 1;
+    for (int i = tid; i < P; i += TOPK_THREADS) keys[i] = i < (int)nc ? cand[(size_t)seg * TK_CAP + i] : ~0ull;
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < P / 2; t += TOPK_THREADS) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+        }
+    }
+    __syncthreads();
+    const int kk = min(k, (int)nc);
+    for (int i = tid; i < k; i += TOPK_THREADS) {
+        float v = -FLT_MAX;
+        int id = 0;
+        if (i < kk) {
+            const unsigned long long e = keys[i];
             v = funord(~(unsigned)(e >> 32));
             id = (int)(unsigned)(e & 0xffffffffu);
         }
@@ -589,7 +712,7 @@ extern "C" int md_delta2bbox(MD_AOT_ARGS) {
 
 extern "C" int md_topk_segmented(MD_AOT_ARGS) {
     // in: scores[T] f32, seg_off[L+1] i32 ; out: values[L,k] f32, indices[L,k] i32, count[L] i32
-    if (nparam != 5) return MD_ERR_NPARAM;
+    if (nparam != 5 && nparam != 6) return MD_ERR_NPARAM;
     if (!params || !extra) return MD_ERR_ARG;
     if (!dtype_is(dtypes, 0, "float32") || !dtype_is(dtypes, 1, "int32") || !dtype_is(dtypes, 2, "float32") ||
         !dtype_is(dtypes, 3, "int32") || !dtype_is(dtypes, 4, "int32"))
@@ -601,9 +724,28 @@ extern "C" int md_topk_segmented(MD_AOT_ARGS) {
     if (numel(ndims, shapes, 2) != L * at->k || numel(ndims, shapes, 3) != L * at->k || numel(ndims, shapes, 4) != L)
         return MD_ERR_ARG;
     if (L == 0) return MD_OK;
-    hipLaunchKernelGGL(topk_segmented_kernel, dim3((unsigned)L), dim3(TOPK_THREADS), 0, (hipStream_t)stream,
-                       (const float *)params[0], (const int *)params[1], at->k, at->min_score, (float *)params[2],
-                       (int *)params[3], (int *)params[4]);
+    hipStream_t s = (hipStream_t)stream;
+    if (at->max_segment > 4 * TK_CHUNK && at->k <= TK_CAP / 2 && L <= 65535) {
+        const size_t hist_bytes = align_up((size_t)L * TK_BINS * 4 + (size_t)L * 4, 256);
+        Scratch ws;
+        int rc = ws.acquire(hist_bytes + (size_t)L * TK_CAP * 8, nparam, params, ndims, shapes, 5, s);
+        if (rc) return rc;
+        unsigned *ghist = (unsigned *)ws.ptr, *cand_cnt = ghist + (size_t)L * TK_BINS;
+        unsigned long long *cand = (unsigned long long *)((char *)ws.ptr + hist_bytes);
+        MD_HIP_TRY(hipMemsetAsync(ws.ptr, 0, hist_bytes, s));
+        const unsigned chunks = (unsigned)((at->max_segment + TK_CHUNK - 1) / TK_CHUNK);
+        hipLaunchKernelGGL(topk_hist_kernel, dim3(chunks, (unsigned)L), dim3(256), 0, s, (const float *)params[0],
+                           (const int *)params[1], at->min_score, ghist);
+        hipLaunchKernelGGL(topk_compact_kernel, dim3(chunks, (unsigned)L), dim3(256), 0, s, (const float *)params[0],
+                           (const int *)params[1], at->k, at->min_score, ghist, cand_cnt, cand);
+        hipLaunchKernelGGL(topk_final_kernel, dim3((unsigned)L), dim3(TOPK_THREADS), 0, s, (const float *)params[0],
+                           (const int *)params[1], at->k, at->min_score, cand_cnt, cand, (float *)params[2],
+                           (int *)params[3], (int *)params[4]);
+    } else {
+        hipLaunchKernelGGL(topk_segmented_kernel, dim3((unsigned)L), dim3(TOPK_THREADS), 0, s, (const float *)params[0],
+                           (const int *)params[1], at->k, at->min_score, (float *)params[2], (int *)params[3],
+                           (int *)params[4]);
+    }
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }

@@ -239,7 +239,7 @@ class _DeltaAttrs(ctypes.Structure):
 
 
 class _TopkAttrs(ctypes.Structure):
-    _fields_ = [("k", ctypes.c_int32), ("min_score", ctypes.c_float)]
+    _fields_ = [("k", ctypes.c_int32), ("min_score", ctypes.c_float), ("max_segment", ctypes.c_int32)]
 
 
 class _RoiAlignAttrs(ctypes.Structure):
@@ -323,7 +323,7 @@ def delta2bbox(rois, deltas, means=(0, 0, 0, 0), stds=(1, 1, 1, 1), max_shape=No
     return out
 
 
-def topk_segmented(scores, seg_offsets, k, min_score=None, out_cnt=None):
+def topk_segmented(scores, seg_offsets, k, min_score=None, out_cnt=None, max_segment=None):
     """scores [T] f32, seg_offsets [L+1] i32 (device) -> (values [L,k], indices [L,k] i32, count [L])."""
     scores = _f32c(scores).reshape(-1)
     L = seg_offsets.numel() - 1
@@ -331,7 +331,8 @@ def topk_segmented(scores, seg_offsets, k, min_score=None, out_cnt=None):
     idx = torch.empty((L, k), dtype=torch.int32, device=scores.device)
     cnt = out_cnt if out_cnt is not None else torch.empty((L,), dtype=torch.int32, device=scores.device)
     _lib.call("md_topk_segmented", [scores, seg_offsets, vals, idx, cnt],
-              extra=_TopkAttrs(int(k), -FLT_MAX if min_score is None else float(min_score)))
+              extra=_TopkAttrs(int(k), -FLT_MAX if min_score is None else float(min_score),
+                               int(scores.numel() if max_segment is None else max_segment)))
     return vals, idx, cnt
 
 
@@ -339,7 +340,7 @@ def top_k(scores2d, k):
     """ops.TopK(sorted=True) on the last axis of a [L, n] tensor."""
     L, n = scores2d.shape
     off = torch.arange(0, (L + 1) * n, n, dtype=torch.int32, device=scores2d.device)
-    v, i, _ = topk_segmented(scores2d.contiguous(), off, k)
+    v, i, _ = topk_segmented(scores2d.contiguous(), off, k, max_segment=n)
     return v, i
 
 

@@ -233,12 +233,13 @@ class RPNHead:
             head = self.out(self.conv(f))                       # [B,H,W,16]
             heads.append(head)
             logits = nn_ops.slice_cast(head, 0, A)              # [B,H,W,A] fp32
-            _, idx, cnt = det_ops.topk_segmented(logits, st["seg"][l], k, out_cnt=counts[l])
+            _, idx, cnt = det_ops.topk_segmented(logits, st["seg"][l], k, out_cnt=counts[l],
+                                                 max_segment=f.shape[1] * f.shape[2] * A)
             det_ops.rpn_decode(head, st["anchors"][l], idx, cnt, A, img_hw, out_boxes=boxes[l], out_scores=scores[l])
         keep, _, _ = det_ops.nms_aligned(boxes.view(L * B, k, 4), self.nms_thr, mode=det_ops.NMS_MODE_STRICT,
                                          count=counts.view(-1))
         mboxes, mscores = det_ops.rpn_merge(boxes, scores, keep.view(L, B, k))
-        topv, topi, cnt = det_ops.topk_segmented(mscores, st["merged_seg"], self.max_per_img)
+        topv, topi, cnt = det_ops.topk_segmented(mscores, st["merged_seg"], self.max_per_img, max_segment=L * k)
         rois, roi_scores = det_ops.make_rois(mboxes, topv, topi, cnt)
         return rois, roi_scores, cnt, dict(heads=heads, boxes=boxes, scores=scores, counts=counts, keep=keep,
                                            mboxes=mboxes, mscores=mscores)
@@ -294,7 +295,7 @@ class StandardRoIHead:
         key = (B, post)
         if key not in self._cache:
             self._cache[key] = torch.arange(0, (B + 1) * post * self.nc, post * self.nc, dtype=torch.int32, device=dev)
-        sv, si, sc = det_ops.topk_segmented(cand, self._cache[key], self.nms_pre)
+        sv, si, sc = det_ops.topk_segmented(cand, self._cache[key], self.nms_pre, max_segment=post * self.nc)
         boxes, labels = det_ops.rcnn_decode_selected(cls_reg, rois, si, sc, self.nc, self.reg_offset, img_hw)
         keep, kidx, num = det_ops.nms_aligned(boxes, self.nms_thr, mode=det_ops.NMS_MODE_STRICT, count=sc, group=labels,
                                               max_output=self.max_per_img)

@@ -15,7 +15,7 @@ from . import _lib
 
 class _ConvAttrs(ctypes.Structure):
     _fields_ = [("kh", ctypes.c_int32), ("kw", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32),
-                ("relu", ctypes.c_int32)]
+                ("relu", ctypes.c_int32), ("variant", ctypes.c_int32)]
 
 
 def cout_tile(cout):
@@ -77,7 +77,10 @@ def conv_out_hw(h, w, pc):
     return (h + 2 * pc.pad - pc.kh) // pc.stride + 1, (w + 2 * pc.pad - pc.kw) // pc.stride + 1
 
 
-def conv2d(x, pc, residual=None, relu=None, out=None):
+CONV_VARIANT = 0  # 0 auto; 1/2/3 force a kernel variant (A/B measurements, see md_conv2d_attrs)
+
+
+def conv2d(x, pc, residual=None, relu=None, out=None, variant=None):
     """x [N,H,W,Cin] bf16 NHWC contiguous CUDA tensor -> y [N,Ho,Wo,Cout] bf16."""
     n, h, w, c = x.shape
     if c != pc.cin:
@@ -85,7 +88,8 @@ def conv2d(x, pc, residual=None, relu=None, out=None):
     ho, wo = conv_out_hw(h, w, pc)
     if out is None:
         out = torch.empty((n, ho, wo, pc.cout), dtype=torch.bfloat16, device=x.device)
-    attrs = _ConvAttrs(pc.kh, pc.kw, pc.stride, pc.pad, int(pc.relu if relu is None else relu))
+    attrs = _ConvAttrs(pc.kh, pc.kw, pc.stride, pc.pad, int(pc.relu if relu is None else relu),
+                       int(CONV_VARIANT if variant is None else variant))
     _lib.call("md_conv2d", [x, pc.w, pc.bias, residual, out], extra=attrs)
     return out
 

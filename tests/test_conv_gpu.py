@@ -29,8 +29,9 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_conv_vs_torch_fp32(case):
+def test_conv_vs_torch_fp32(case, variant):
     from minddet_amd import nn_ops
 
     name, N, H, W, Cin, Cout, k, stride, pad, relu, use_res, use_bn = case
@@ -51,7 +52,7 @@ def test_conv_vs_torch_fp32(case):
     res = None
     if use_res:
         res = torch.randn((N, ho, wo, pc.cout), generator=g).to(torch.bfloat16)
-    y = nn_ops.conv2d(xb.to(DEV), pc, residual=None if res is None else res.to(DEV))
+    y = nn_ops.conv2d(xb.to(DEV), pc, residual=None if res is None else res.to(DEV), variant=variant)
     torch.cuda.synchronize()
     y = y.float().cpu()
     # fp32 reference on the same bf16-rounded operands
