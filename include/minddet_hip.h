@@ -115,6 +115,14 @@ typedef struct md_conv2d_attrs {
     int32_t relu;                /* 1: ReLU after bias (+ residual) */
     int32_t variant;             /* 0 = auto (default). Tile/staging variant for A/B measurements:
                                     1 register-staged 128x128, 2 LDS-DMA 128x128, 3 LDS-DMA 256x256 */
+    /* generalised addressing, used when adv != 0 (all zero = plain conv).  The op then computes, for
+     * ho < sub_h, wo < sub_w:  y[n, ho*out_stride + out_off_y, wo*out_stride + out_off_x, c_off + c] =
+     * act(bias[c] + sum x[n, ho*stride - pad_top + kh, wo*stride - pad_left + kw, ci] * w[c,kh,kw,ci]), c < cout.
+     * This is how transposed convs (one launch per output-pixel parity, Conv2dTranspose k=4 s=2 p=1 of
+     * centernet/src/centernet_det.py:145-152 and k=s of centerpoint/det3d_ms/models/necks/rpn.py:66-80)
+     * and channel-concatenated outputs (rpn.py:152, pointpillars.py:598) run on the same MFMA kernel. */
+    int32_t adv;
+    int32_t pad_top, pad_left, sub_h, sub_w, out_stride, out_off_y, out_off_x, c_off, cout;
 } md_conv2d_attrs;
 /* Replaces Conv2d -> BatchNorm2d(eval) -> [+ residual] -> ReLU of the reference graphs
  * (centernet/src/resnet.py:109-178,181-252; centerpoint/det3d_ms/models/necks/rpn.py:9-154).
@@ -146,6 +154,8 @@ typedef struct md_slice_attrs {
 } md_slice_attrs;
 /* in x[..., C] bf16 ; out y[..., width] f32 = x[..., c0:c0+width].  extra: md_slice_attrs. */
 int md_slice_cast(MD_AOT_ARGS);
+/* in x[N,H,W,C] bf16 ; out y[N,width,H,W] f32 (NCHW, the layout centernet/src/decode.py consumes) */
+int md_nhwc_to_nchw_f32(MD_AOT_ARGS);
 
 /* ------------------------------------------------------------------------------------------
  * Anchor / prior generation

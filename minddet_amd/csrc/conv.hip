@@ -45,6 +45,12 @@ struct ConvArgs {
     int cpt;      // chunks (8 ch) per tap = Cin/8
     int n_ptiles, n_ctiles, pt_per_xcd;
     unsigned x_bytes, w_bytes;  // buffer sizes for the LDS-DMA descriptors (< 2 GiB each)
+    // generalised addressing (sub-pixel transposed conv, channel-concat outputs); plain conv: pad_top = pad_left
+    // = pad, (Ho,Wo) is the full output, os = 1, oy = ox = c_off = 0, Ctot = Cout
+    int pad_top, pad_left;  // input window origin = (ho*stride - pad_top, wo*stride - pad_left)
+    int Hf, Wf, Ctot;       // full output tensor dims [N,Hf,Wf,Ctot]
+    int os, oy, ox, c_off;  // output pixel (ho*os + oy, wo*os + ox), channels [c_off, c_off + Cout)
+    int adv;                // 0: plain (off = m*Cout + c)
 };
 
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((unsigned)v << 16); }
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         if (m < a.M) {
             const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
             const int ho = r / a.Wo, wo = r - ho * a.Wo;
-            const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+            const int hi0 = ho * a.stride - a.pad_top, wi0 = wo * a.stride - a.pad_left;
             p_hw0[i] = (hi0 << 16) | (wi0 & 0xffff);
             if constexpr (MODE == 0) p_base[i] = n * a.H * a.W;
             else p_base[i] = (((n * a.H + hi0) * a.W + wi0) * a.Cin) * 2 + (MODE == 2 ? chunk * 16 : 0);
@@ -267,6 +273,12 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
     // ---- epilogue.  Residual rows are fetched first so that their HBM latency overlaps the LDS transpose.
     constexpr int CPP = CT / 8;                 // 16-B chunks per pixel row of the tile
     constexpr int EP_ITERS = PT * CPP / NT;     // chunks per thread
+    auto out_offset = [&](int m, int c) -> size_t {
+        if (!a.adv) return (size_t)m * a.Cout + c;
+        const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
+        const int ho = r / a.Wo, wo = r - ho * a.Wo;
+        return (((size_t)n * a.Hf + ho * a.os + a.oy) * a.Wf + wo * a.os + a.ox) * a.Ctot + a.c_off + c;
+    };
     u32x4 rres[EP_ITERS];
     if (a.res) {
 #pragma unroll
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
             const int p_local = e / CPP, cc = e % CPP;
             const int m = pix0 + p_local, c = cout0 + cc * 8;
             rres[it] = (u32x4){0u, 0u, 0u, 0u};
-            if (m < a.M && c < a.Cout) rres[it] = *reinterpret_cast<const u32x4 *>(a.res + (size_t)m * a.Cout + c);
+            if (m < a.M && c < a.Cout) rres[it] = *reinterpret_cast<const u32x4 *>(a.res + out_offset(m, c));
         }
     }
     // bias (+ReLU when no residual) -> bf16x4 -> LDS [pixel][cout] image
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         const int m = pix0 + p_local, c = cout0 + cc * 8;
         if (m >= a.M || c >= a.Cout) continue;
         u32x4 v = *reinterpret_cast<const u32x4 *>(E + p_local * EP_STRIDE + cc * 16);
-        const size_t off = (size_t)m * a.Cout + c;
+        const size_t off = out_offset(m, c);
         if (a.res) {
             const u32x4 rv = rres[it];
 #pragma unroll
@@ -371,12 +383,25 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     a.res = (const uint16_t *)params[3];
     a.y = (uint16_t *)params[4];
     a.N = (int)shapes[0][0]; a.H = (int)shapes[0][1]; a.W = (int)shapes[0][2]; a.Cin = (int)shapes[0][3];
-    a.Ho = (int)shapes[4][1]; a.Wo = (int)shapes[4][2]; a.Cout = (int)shapes[4][3];
+    a.Hf = (int)shapes[4][1]; a.Wf = (int)shapes[4][2]; a.Ctot = (int)shapes[4][3];
     a.kh = at->kh; a.kw = at->kw; a.stride = at->stride; a.pad = at->pad; a.relu = at->relu;
     if (a.kh < 1 || a.kw < 1 || a.stride < 1 || a.pad < 0) return MD_ERR_ARG;
-    if (a.Cin % 8 || a.Cout % 8 || shapes[4][0] != a.N) return MD_ERR_ARG;
-    if (a.Ho != (a.H + 2 * a.pad - a.kh) / a.stride + 1 || a.Wo != (a.W + 2 * a.pad - a.kw) / a.stride + 1)
-        return MD_ERR_ARG;
+    a.adv = at->adv != 0;
+    if (!a.adv) {
+        a.Ho = a.Hf; a.Wo = a.Wf; a.Cout = a.Ctot;
+        a.pad_top = a.pad_left = a.pad; a.os = 1; a.oy = a.ox = a.c_off = 0;
+        if (a.Ho != (a.H + 2 * a.pad - a.kh) / a.stride + 1 || a.Wo != (a.W + 2 * a.pad - a.kw) / a.stride + 1)
+            return MD_ERR_ARG;
+    } else {
+        a.Ho = at->sub_h; a.Wo = at->sub_w; a.Cout = at->cout;
+        a.pad_top = at->pad_top; a.pad_left = at->pad_left;
+        a.os = at->out_stride; a.oy = at->out_off_y; a.ox = at->out_off_x; a.c_off = at->c_off;
+        if (a.Ho < 1 || a.Wo < 1 || a.os < 1 || a.oy < 0 || a.ox < 0 || a.c_off < 0 || a.c_off % 8 || a.Cout < 8) return MD_ERR_ARG;
+        if (a.pad_top < 0 || a.pad_left < 0 || a.pad_top > 16384 || a.pad_left > 16384) return MD_ERR_ARG;
+        // every written element must lie inside the output tensor
+        if ((a.Ho - 1) * a.os + a.oy >= a.Hf || (a.Wo - 1) * a.os + a.ox >= a.Wf || a.c_off + a.Cout > a.Ctot) return MD_ERR_ARG;
+    }
+    if (a.Cin % 8 || a.Cout % 8 || a.Ctot % 8 || shapes[4][0] != a.N) return MD_ERR_ARG;
     a.Kreal = a.kh * a.kw * a.Cin;
     a.Kpad = (int)shapes[1][1];
     const int ctile = md_conv2d_cout_tile(a.Cout);

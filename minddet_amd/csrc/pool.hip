@@ -104,6 +104,24 @@ __global__ void slice_cast_kernel(const uint16_t *__restrict__ in, float *__rest
     }
 }
 
+// out[n, j, h, w] = float(in[n, h, w, c0 + j]): the head tensors the reference decodes are NCHW fp32
+// (centernet/src/decode.py:151-196); LDS-tiled transpose so both sides move whole lines.
+__global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const uint16_t *__restrict__ in, float *__restrict__ out,
+                                                               int HW, int C, int c0, int cw) {
+    __shared__ float tile[64][65];
+    const int n = blockIdx.z, p0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {   // r: pixel within tile, tx: channel
+        const int p = p0 + r, j = j0 + tx;
+        tile[r][tx] = (p < HW && j < cw) ? pbf2f(in[((size_t)n * HW + p) * C + c0 + j]) : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {   // r: channel within tile, tx: pixel
+        const int j = j0 + r, p = p0 + tx;
+        if (j < cw && p < HW) out[((size_t)n * cw + j) * HW + p] = tile[tx][r];
+    }
+}
+
 static inline unsigned grid_for(size_t total) {
     size_t b = (total + 255) / 256;
     return (unsigned)(b > 8192 ? 8192 : (b == 0 ? 1 : b));
@@ -146,6 +164,24 @@ extern "C" int md_upsample_add(MD_AOT_ARGS) {
     if (total == 0) return MD_OK;
     hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t *)params[0], (const uint16_t *)params[1], (uint16_t *)params[2], N, H, W, C, Ht, Wt);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+
+extern "C" int md_nhwc_to_nchw_f32(MD_AOT_ARGS) {
+    // in x[N,H,W,C] bf16 ; out y[N,width,H,W] f32 = x[..., c0:c0+width] transposed.  extra: md_slice_attrs
+    if (nparam != 2) return MD_ERR_NPARAM;
+    if (!params || !extra || !ndims || !shapes || ndims[0] != 4 || ndims[1] != 4) return MD_ERR_ARG;
+    if (!dtype_is(dtypes, 0, "bfloat16") || !dtype_is(dtypes, 1, "float32")) return MD_ERR_ARG;
+    const md_slice_attrs *at = (const md_slice_attrs *)extra;
+    const int N = (int)shapes[0][0], H = (int)shapes[0][1], W = (int)shapes[0][2], C = (int)shapes[0][3];
+    if (at->c0 < 0 || at->width < 1 || at->c0 + at->width > C) return MD_ERR_ARG;
+    if (shapes[1][0] != N || shapes[1][1] != at->width || shapes[1][2] != H || shapes[1][3] != W) return MD_ERR_ARG;
+    if ((size_t)N * H * W == 0) return MD_OK;
+    if (N > 65535) return MD_ERR_SIZE;
+    const int HW = H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3((HW + 63) / 64, (at->width + 63) / 64, N), dim3(256), 0,
+                       (hipStream_t)stream, (const uint16_t *)params[0], (float *)params[1], HW, C, at->c0, at->width);
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }

@@ -376,3 +376,158 @@ class FasterRCNN:
         for m in self.roi_head.modules():
             total += r * m.cout * m.cin
         return total
+
+
+# ----------------------------------------------------------------------------- CenterNet (reference-present graph)
+class DeconvModule:
+    """Conv2dTranspose [+ BatchNorm2d] [+ ReLU] -> s*s sub-pixel md_conv2d launches (nn_ops.pack_conv_transpose)."""
+
+    def __init__(self, init, cin, cout, k, stride, pad, bn=True, relu=True, bn_eps=1e-5):
+        self.cin, self.cout, self.k, self.stride, self.pad, self.relu = cin, cout, k, stride, pad, relu
+        std = math.sqrt(2.0 / (k * k * cout))
+        self.weight_t = torch.from_numpy(init.rng.normal(0.0, std, (cin, cout, k, k)).astype(np.float32))
+        self.bn = init.bn(cout, bn_eps) if bn else None
+        self.packed = None
+
+    def to(self, device):
+        self.packed = nn_ops.pack_conv_transpose(self.weight_t, bn=self.bn, stride=self.stride, pad=self.pad,
+                                                 relu=self.relu).to(device)
+        return self
+
+    def __call__(self, x, out=None, c_off=0):
+        return nn_ops.conv_transpose2d(x, self.packed, out=out, c_off=c_off)
+
+
+@DETECTORS.register_module
+class CenterNet:
+    """centernet/src/centernet_det.py:79-174 (GatherDetectionFeatureCell) + :374-399 (CenterNetDetEval):
+    ResNet-18 -> 3 x [3x3 conv + BN + ReLU, Conv2dTranspose 4x4 s2 p1 + BN + ReLU] (512->256->128->64)
+    -> hm / wh / reg heads (3x3 conv 64 + ReLU, 1x1 conv; hm bias -2.19, :29-69) -> sigmoid+clip ->
+    DetectionDecode (decode.py:123-196).
+    Deviation, as SURVEY 7.5 plans: the three ModulatedDeformConv2d 3x3 layers (DCNv2, resnet.py:24-106,
+    arithmetic inside un-vendored MindSpore) are plain 3x3 convs here.
+    The three heads are evaluated as one fused 3x3 conv (64 -> 3*head_conv) and one block-diagonal 1x1
+    conv (same arithmetic per output: the off-block weights are exact zeros)."""
+
+    def __init__(self, depth=18, num_classes=80, head_conv=64, K=100, base_width=64, seed=7, train_cfg=None,
+                 test_cfg=None):
+        init = ParamInit(seed)
+        self.backbone = ResNet(depth, base_width=base_width, init=init)
+        cin = self.backbone.out_channels[-1]
+        self.neck = []
+        for cout in (base_width * 4, base_width * 2, base_width):
+            self.neck.append(ConvModule(init, cin, cout, 3, 1, 1))
+            self.neck.append(DeconvModule(init, cout, cout, 4, 2, 1))
+            cin = cout
+        self.num_classes, self.head_conv, self.K = num_classes, head_conv, K
+        hc = head_conv
+        self.heads = {}
+        for name, cout, b2 in (("hm", num_classes, -2.19), ("wh", 2, 0.0), ("reg", 2, 0.0)):
+            std = None if name == "hm" else 0.001
+            c1 = ConvModule(init, cin, hc, 3, 1, 1, bn=False, relu=True, bias=True, std=std,
+                            bias_value=None if name == "hm" else 0.0)
+            c2 = ConvModule(init, hc, cout, 1, bn=False, relu=False, bias=True, std=std, bias_value=b2)
+            self.heads[name] = (c1, c2)
+        # fused forms
+        self.head1 = ConvModule(init, cin, 3 * hc, 3, 1, 1, bn=False, relu=True, bias=True)
+        self.head1.weight = torch.cat([self.heads[n][0].weight for n in ("hm", "wh", "reg")], 0)
+        self.head1.bias = torch.cat([self.heads[n][0].bias for n in ("hm", "wh", "reg")], 0)
+        self.n_out = num_classes + 4
+        self.head2 = ConvModule(init, 3 * hc, self.n_out, 1, bn=False, relu=False, bias=True)
+        w2 = torch.zeros((self.n_out, 3 * hc, 1, 1))
+        b2 = torch.zeros((self.n_out,))
+        o = 0
+        for i, n in enumerate(("hm", "wh", "reg")):
+            c2 = self.heads[n][1]
+            w2[o:o + c2.cout, i * hc:(i + 1) * hc] = c2.weight
+            b2[o:o + c2.cout] = c2.bias
+            o += c2.cout
+        self.head2.weight, self.head2.bias = w2, b2
+        self.decode = det_ops.DetectionDecode(reg_offset=True, K=K)
+
+    def conv_modules(self):
+        return self.backbone.modules() + self.neck + [self.head1, self.head2]
+
+    def to(self, device):
+        for m in self.conv_modules():
+            m.to(device)
+        return self
+
+    def features(self, images):
+        x = self.backbone(images)[-1]
+        for m in self.neck:
+            x = m(x)
+        return self.head2(self.head1(x))  # [B, H/4, W/4, roundup8(num_classes + 4)]
+
+    def forward(self, images, return_aux=False):
+        head = self.features(images)
+        nc = self.num_classes
+        hm = det_ops.sigmoid_clip(nn_ops.nhwc_to_nchw_f32(head, 0, nc))
+        wh = nn_ops.nhwc_to_nchw_f32(head, nc, 2)
+        reg = nn_ops.nhwc_to_nchw_f32(head, nc + 2, 2)
+        det, inds, cls = self.decode({"hm": hm, "wh": wh, "reg": reg}, return_indices=True)
+        if return_aux:
+            return det, dict(head=head, hm=hm, wh=wh, reg=reg, inds=inds, cls=cls)
+        return det
+
+    __call__ = forward
+
+
+# ----------------------------------------------------------------------------- CenterPoint RPN neck
+@NECKS.register_module
+class RPN:
+    """centerpoint/det3d_ms/models/necks/rpn.py:9-154: per stage [Pad1 + Conv3x3(stride) + BN(eps 1e-3) + ReLU]
+    + n x [Conv3x3 + BN + ReLU]; deblocks = Conv2dTranspose(k=s, stride s) or strided Conv2d(k, stride k)
+    + BN + ReLU; channel concat -> [B, H/ds, W/ds, sum(us_num_filters)].  The concat is free: every deblock
+    writes its channel slice of the output directly (md_conv2d c_off)."""
+
+    def __init__(self, layer_nums=(3, 5, 5), ds_layer_strides=(2, 2, 2), ds_num_filters=(64, 128, 256),
+                 us_layer_strides=(0.5, 1, 2), us_num_filters=(128, 128, 128), num_input_features=64, norm_cfg=None,
+                 seed=7, **kwargs):
+        init = ParamInit(seed)
+        eps = (norm_cfg or {}).get("eps", 1e-3)
+        self.blocks, self.deblocks = [], []
+        cin = num_input_features
+        self.up_start = len(layer_nums) - len(us_layer_strides)
+        for i, n in enumerate(layer_nums):
+            blk = [ConvModule(init, cin, ds_num_filters[i], 3, ds_layer_strides[i], 1, bn_eps=eps)]
+            blk += [ConvModule(init, ds_num_filters[i], ds_num_filters[i], 3, 1, 1, bn_eps=eps) for _ in range(n)]
+            self.blocks.append(blk)
+            cin = ds_num_filters[i]
+            if i - self.up_start >= 0:
+                s = us_layer_strides[i - self.up_start]
+                cout = us_num_filters[i - self.up_start]
+                if s > 1:
+                    self.deblocks.append(DeconvModule(init, cin, cout, int(s), int(s), 0, bn_eps=eps))
+                else:
+                    k = int(round(1 / s))
+                    self.deblocks.append(ConvModule(init, cin, cout, k, k, 0, bn_eps=eps))
+        self.out_channels = sum(us_num_filters)
+
+    def modules(self):
+        return [m for b in self.blocks for m in b] + self.deblocks
+
+    def to(self, device):
+        for m in self.modules():
+            m.to(device)
+        return self
+
+    def __call__(self, x):
+        out, c_off = None, 0
+        for i, blk in enumerate(self.blocks):
+            for m in blk:
+                x = m(x)
+            if i - self.up_start >= 0:
+                d = self.deblocks[i - self.up_start]
+                if out is None:
+                    if isinstance(d, DeconvModule):
+                        oh, ow = x.shape[1] * d.stride, x.shape[2] * d.stride
+                    else:
+                        oh, ow = nn_ops.conv_out_hw(x.shape[1], x.shape[2], d.packed)
+                    out = torch.empty((x.shape[0], oh, ow, self.out_channels), dtype=torch.bfloat16, device=x.device)
+                if isinstance(d, DeconvModule):
+                    d(x, out=out, c_off=c_off)
+                else:
+                    nn_ops.conv2d(x, d.packed, out=out, c_off=c_off)
+                c_off += d.cout
+        return out

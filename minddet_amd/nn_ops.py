@@ -15,7 +15,10 @@ from . import _lib
 
 class _ConvAttrs(ctypes.Structure):
     _fields_ = [("kh", ctypes.c_int32), ("kw", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32),
-                ("relu", ctypes.c_int32), ("variant", ctypes.c_int32)]
+                ("relu", ctypes.c_int32), ("variant", ctypes.c_int32), ("adv", ctypes.c_int32), ("pad_top", ctypes.c_int32),
+                ("pad_left", ctypes.c_int32), ("sub_h", ctypes.c_int32), ("sub_w", ctypes.c_int32),
+                ("out_stride", ctypes.c_int32), ("out_off_y", ctypes.c_int32), ("out_off_x", ctypes.c_int32),
+                ("c_off", ctypes.c_int32), ("cout", ctypes.c_int32)]
 
 
 def cout_tile(cout):
@@ -80,8 +83,10 @@ def conv_out_hw(h, w, pc):
 CONV_VARIANT = 0  # 0 auto; 1/2/3 force a kernel variant (A/B measurements, see md_conv2d_attrs)
 
 
-def conv2d(x, pc, residual=None, relu=None, out=None, variant=None):
-    """x [N,H,W,Cin] bf16 NHWC contiguous CUDA tensor -> y [N,Ho,Wo,Cout] bf16."""
+def conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0):
+    """x [N,H,W,Cin] bf16 NHWC contiguous CUDA tensor -> y [N,Ho,Wo,Cout] bf16.
+    With `out` wider than the layer (channel concat, rpn.py:152) the result goes to channels
+    [c_off, c_off + Cout) of `out`."""
     n, h, w, c = x.shape
     if c != pc.cin:
         raise _lib.MindDetHipError(f"conv2d: input has {c} channels, layer packed for {pc.cin}")
@@ -90,7 +95,60 @@ def conv2d(x, pc, residual=None, relu=None, out=None, variant=None):
         out = torch.empty((n, ho, wo, pc.cout), dtype=torch.bfloat16, device=x.device)
     attrs = _ConvAttrs(pc.kh, pc.kw, pc.stride, pc.pad, int(pc.relu if relu is None else relu),
                        int(CONV_VARIANT if variant is None else variant))
+    if out.shape[3] != pc.cout or c_off:
+        attrs.adv, attrs.pad_top, attrs.pad_left, attrs.sub_h, attrs.sub_w = 1, pc.pad, pc.pad, ho, wo
+        attrs.out_stride, attrs.c_off, attrs.cout = 1, int(c_off), pc.cout
     _lib.call("md_conv2d", [x, pc.w, pc.bias, residual, out], extra=attrs)
+    return out
+
+
+class PackedConvT:
+    """A transposed conv as s*s sub-pixel convs on the MFMA kernel (one launch per output parity)."""
+
+    def __init__(self, subs, cin, cout, k, stride, relu):
+        self.subs, self.cin, self.cout, self.k, self.stride, self.relu = subs, cin, cout, k, stride, relu
+
+    def to(self, device):
+        for pc, _ in self.subs:
+            pc.to(device)
+        return self
+
+
+def pack_conv_transpose(weight_t, bias=None, bn=None, stride=2, pad=1, relu=False):
+    """weight_t [Cin,Cout,k,k] (MindSpore/PyTorch Conv2dTranspose layout).  Supported: (k=4,s=2,p=1) --
+    centernet/src/centernet_det.py:145-152 -- and (k=s, p=0) -- centerpoint/det3d_ms/models/necks/rpn.py:66-80.
+    Output pixel oy = iy*s - p + ky  =>  for output parity py the contributing kernel rows are
+    ky = (py + p) mod s, +s, ... each paired with input row iy = (oy + p - ky) / s."""
+    cin, cout, k, k2 = weight_t.shape
+    s = stride
+    if not (k == k2 and ((k == 4 and s == 2 and pad == 1) or (k == s and pad == 0))):
+        raise _lib.MindDetHipError("pack_conv_transpose: unsupported (kernel, stride, padding)")
+    subs = []
+    for py in range(s):
+        for px in range(s):
+            kys = [ky for ky in range(k) if (ky - py - pad) % s == 0]
+            kxs = [kx for kx in range(k) if (kx - px - pad) % s == 0]
+            # input row for output row oy = s*i + py and kernel row ky: iy = i + (py + pad - ky)/s ; order taps by iy
+            dys = sorted(((py + pad - ky) // s, ky) for ky in kys)
+            dxs = sorted(((px + pad - kx) // s, kx) for kx in kxs)
+            w_sub = torch.stack([torch.stack([weight_t[:, :, ky, kx] for _, kx in dxs], -1) for _, ky in dys], -2)
+            # [Cin, Cout, nty, ntx] -> conv layout [Cout, Cin, nty, ntx]
+            pc = pack_conv(w_sub.permute(1, 0, 2, 3).contiguous(), bias=bias, bn=bn, stride=1, pad=0, relu=relu)
+            subs.append((pc, dict(py=py, px=px, pad_top=-dys[0][0], pad_left=-dxs[0][0])))
+    return PackedConvT(subs, cin, cout, k, s, relu)
+
+
+def conv_transpose2d(x, pct, out=None, c_off=0):
+    n, h, w, c = x.shape
+    s = pct.stride
+    c_out = pct.subs[0][0].cout
+    if out is None:
+        out = torch.empty((n, h * s, w * s, c_out), dtype=torch.bfloat16, device=x.device)
+    for pc, m in pct.subs:
+        attrs = _ConvAttrs(pc.kh, pc.kw, 1, 0, int(pct.relu), int(CONV_VARIANT))
+        attrs.adv, attrs.pad_top, attrs.pad_left, attrs.sub_h, attrs.sub_w = 1, m["pad_top"], m["pad_left"], h, w
+        attrs.out_stride, attrs.out_off_y, attrs.out_off_x, attrs.c_off, attrs.cout = s, m["py"], m["px"], int(c_off), pc.cout
+        _lib.call("md_conv2d", [x, pc.w, pc.bias, None, out], extra=attrs)
     return out
 
 
@@ -130,4 +188,12 @@ def slice_cast(x, c0, width):
     """x[..., c0:c0+width] (bf16) -> fp32 contiguous."""
     y = torch.empty(tuple(x.shape[:-1]) + (width,), dtype=torch.float32, device=x.device)
     _lib.call("md_slice_cast", [x, y], extra=_SliceAttrs(c0, width))
+    return y
+
+
+def nhwc_to_nchw_f32(x, c0, width):
+    """x [N,H,W,C] bf16 -> [N,width,H,W] fp32 (channels c0..c0+width)."""
+    n, h, w, _ = x.shape
+    y = torch.empty((n, width, h, w), dtype=torch.float32, device=x.device)
+    _lib.call("md_nhwc_to_nchw_f32", [x, y], extra=_SliceAttrs(c0, width))
     return y

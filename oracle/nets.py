@@ -212,3 +212,42 @@ def faster_rcnn_forward(model, images_nhwc, quant=False):
     dets, count, _ = rcnn_finish(cand, cls_reg, rois, roi.nc, roi.reg_offset, (H, W), roi.nms_pre, roi.nms_thr,
                                  roi.max_per_img, post)
     return dets, count
+
+
+# ----------------------------------------------------------------------------- CenterNet / CenterPoint RPN oracles
+def deconv_module(m, x, quant=False):
+    """Conv2dTranspose + BN(eval) + ReLU on NCHW fp32 (weight layout [Cin,Cout,k,k])."""
+    w = m.weight_t.float()
+    if m.bn is not None:
+        gamma, beta, mean, var, eps = m.bn
+        scale = gamma / torch.sqrt(var + eps)
+        w = w * scale.view(1, -1, 1, 1)
+        b = beta - mean * scale
+    else:
+        b = torch.zeros(w.shape[1])
+    y = F.conv_transpose2d(x, _q(w, quant), b, stride=m.stride, padding=m.pad)
+    if m.relu:
+        y = torch.relu(y)
+    return _q(y, quant)
+
+
+def centernet_features(model, x, quant=False):
+    """centernet/src/centernet_det.py:162-174 with the UNFUSED heads (three 3x3 + three 1x1 convs)."""
+    f = resnet_forward(model.backbone, x, quant)[-1]
+    for m in model.neck:
+        f = deconv_module(m, f, quant) if hasattr(m, "weight_t") else conv_module(m, f, quant=quant)
+    out = {}
+    for name, (c1, c2) in model.heads.items():
+        out[name] = conv_module(c2, conv_module(c1, f, quant=quant), quant=quant)
+    return out
+
+
+def rpn_neck_forward(neck, x, quant=False):
+    ups = []
+    for i, blk in enumerate(neck.blocks):
+        for m in blk:
+            x = conv_module(m, x, quant=quant)
+        if i - neck.up_start >= 0:
+            d = neck.deblocks[i - neck.up_start]
+            ups.append(deconv_module(d, x, quant) if hasattr(d, "weight_t") else conv_module(d, x, quant=quant))
+    return torch.cat(ups, 1)

@@ -1,0 +1,32 @@
+"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) into the
+HBM traffic of the dominant kernel, corrected as MI355X_MICROARCH.md (HBM section) prescribes for gfx950:
+FETCH_SIZE (KB) reports half of the bytes of wide coalesced reads -> x2; WRITE_SIZE (KB) is exact for 16-B
+streaming stores.  Usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <steps_profiled> <out.json>"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(d):
+    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"]][0] += float(r["Counter_Value"])
+        agg[r["Kernel_Name"]][1] += 1
+    return agg
+
+
+fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+steps = int(sys.argv[3])
+conv = [k for k in fetch if "conv_igemm_kernel" in k]
+f_kb = sum(fetch[k][0] for k in conv)
+w_kb = sum(write[k][0] for k in conv)
+n = sum(fetch[k][1] for k in conv)
+out = {"kernel": "conv_igemm_kernel (all instantiations)", "profiled_steps": steps, "launches": n,
+       "FETCH_SIZE_KB_raw": f_kb, "WRITE_SIZE_KB": w_kb, "fetch_correction": 2.0,
+       "hbm_bytes_per_step": (2.0 * f_kb + w_kb) * 1024 / steps,
+       "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024 / n}
+json.dump(out, open(sys.argv[4], "w"), indent=1)
+print(out)
