@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (guide: ~2.5 PF)
+PEAK_HBM_BPS = 8.0e12      # HBM3E spec peak (guide: 8 TB/s, ~6.3 achievable)
 
 
 def main():
@@ -74,7 +75,8 @@ def main():
         y = orig_conv2d(x, pc, residual=residual, relu=relu, out=out)
         e1.record()
         n, ho, wo, _ = y.shape
-        records.append((e0, e1, 2.0 * n * ho * wo * pc.cout * pc.cin_real * pc.kh * pc.kw, tuple(x.shape), pc.cout, pc.kh))
+        byts = 2.0 * (x.numel() + y.numel() + pc.cout * pc.cin_real * pc.kh * pc.kw + (residual.numel() if residual is not None else 0))
+        records.append((e0, e1, 2.0 * n * ho * wo * pc.cout * pc.cin_real * pc.kh * pc.kw, tuple(x.shape), pc.cout, pc.kh, byts))
         return y
 
     def step():
@@ -109,16 +111,27 @@ def main():
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in records)
         tot_fl = sum(r[2] for r in records)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        # layer-wise roofline: each launch is bounded by max(flops / MFMA peak, algorithmic bytes / HBM peak)
+        t_roof_ms = sum(max(r[2] / (PEAK_BF16_TFLOPS * 1e12), r[6] / PEAK_HBM_BPS) for r in records) * 1e3
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+        if os.path.exists(tp):  # PMC passes are separate rocprofv3 runs (tools/pmc_traffic.py); same config only
+            tj = json.load(open(tp))
+            if tj.get("batch_per_gpu") == B:
+                traffic = round(tj["hbm_bytes_per_launch"] / 1e6, 2)
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (implicit-GEMM conv/FC, all launches)",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                    "traffic": None, "launches_per_step": len(records) // max(args.steps, 1),
+                    "traffic": traffic, "traffic_unit": "MB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_conv_traffic.json)",
+                    "algorithmic_mb_per_launch": round(sum(r[6] for r in records) / len(records) / 1e6, 2),
+                    "frac_of_layerwise_roofline": round(t_roof_ms / tot_ms, 4),
+                    "launches_per_step": len(records) // max(args.steps, 1),
                     "avg_launch_us": round(tot_ms * 1e3 / len(records), 2),
                     "conv_ms_per_step": round(tot_ms / max(args.steps, 1), 3),
                     "algorithmic_gflop_per_step": round(tot_fl / max(args.steps, 1) / 1e9, 1)}
 
     if args.dump_convs and rank == 0 and records:
         per = {}
-        for e0, e1, fl, xs, cout, k in records:
+        for e0, e1, fl, xs, cout, k, _b in records:
             key = f"{xs}->{cout} k{k}"
             d = per.setdefault(key, [0.0, 0.0, 0])
             d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += 1

@@ -29,6 +29,7 @@ namespace md {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 struct ConvArgs {
@@ -80,21 +81,38 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 
 //         activation row (tap-validity bit -> select the out-of-range offset) and none on weights.
 // The LDS image of a DMA is lane-linear per wave instruction (8 rows x 128 B), so the XOR swizzle is
 // applied to the per-lane SOURCE chunk and to the fragment reads, never to the destination.
-template <int NT, int WC, int WP, int FC, int FP, int MODE>
+// PIPE 0: two LDS stages, every wave waits for its DMAs (vmcnt 0) at the barrier of each K tile.
+// PIPE 1: three-stage LDS ring, prefetch distance two tiles, COUNTED vmcnt (one stage stays in flight across
+//         the barrier), and the two waves that share a SIMD (w, w+4) issue their DMAs at opposite ends of
+//         the iteration, so one wave's DMA issue overlaps its partner's MFMA cluster.  MODE 2, 8 waves.
+// MF 0: v_mfma_f32_32x32x16_bf16 (FC x FP tiles of 32x32 per wave); MF 1: v_mfma_f32_16x16x32_bf16 (2FC x 2FP
+// tiles of 16x16, K 32 per instruction): same LDS traffic and cycles per flop, but the chip holds a higher
+// clock on the 16x16 shape under load (MI355X_MICROARCH.md, DVFS give-back item 7).
+template <int NT, int WC, int WP, int FC, int FP, int MODE, int PIPE = 0, int MF = 0>
 __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr bool GLDS = MODE != 0;
+    static_assert(PIPE == 0 || (MODE == 2 && NT == 512), "the 3-stage ring is built for the LDS-DMA fast path, 8 waves");
+    // PIPE 2: PRODUCER / CONSUMER waves.  Measured on the PIPE-0 kernel (tools/conv_ab.py ablations, r01): staging
+    // alone takes ~60 % of the kernel time, the MFMAs alone ~35 %, and the two do not overlap -- an in-order wave
+    // that is stalled issuing LDS-DMA (TA back-pressure) cannot issue its MFMAs.  Here waves [0, NT/128) only
+    // compute and waves [NT/128, NT/64) only stage: one barrier per K tile hands a landed stage over.
+    constexpr bool SPEC = PIPE == 2;
+    constexpr int NTC = SPEC ? NT / 2 : NT;  // threads that compute (and threads that stage)
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
-    constexpr int RPP = NT / 8;                            // tile rows staged per pass of the workgroup
+    constexpr int RPP = (PIPE == 2 ? NT / 2 : NT) / 8;     // tile rows staged per pass of the staging threads
     constexpr int A_ROWS = CT / RPP, B_ROWS = PT / RPP;    // 16-B chunks per thread per tile
     constexpr int TILE_BYTES = (CT + PT) * ROWB;
     constexpr int EP_STRIDE = CT * 2 + 16;                 // epilogue image row stride (bytes)
     constexpr unsigned OOR = 0x80000000u;                  // byte offset past any buffer (< 2 GiB): reads as 0
-    static_assert(WC * WP * 64 == NT, "wave grid must cover the workgroup");
+    static_assert(WC * WP * 64 == (PIPE == 2 ? NT / 2 : NT), "wave grid must cover the compute waves");
     static_assert(CT % RPP == 0 && PT % RPP == 0, "tile rows must be a multiple of the staging pass");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wc = wave / WP, wp = wave % WP;
+    const bool is_loader = SPEC && __builtin_amdgcn_readfirstlane(tid) >= NTC;
+    const int cwave = SPEC ? (wave & (NTC / 64 - 1)) : wave;  // index inside the compute (or staging) group
+    const int wc = cwave / WP, wp = cwave % WP;
+    const int stid = SPEC ? (tid & (NTC - 1)) : tid;           // staging thread index
     // XCD-aware tile map (workgroups are dealt round-robin over the 8 XCDs, each with a private L2):
     // every XCD owns a CONTIGUOUS range of pixel tiles, and inside it the cout tile varies fastest, so the
     // workgroups that share an activation tile (and the 3x3 halo rows of its neighbours) hit the same L2.
@@ -106,8 +124,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
 
     // this thread stages rows row0 + RPP*i; physical 16-B slot (tid & 7) of the row holds LOGICAL k-chunk
     // `chunk` (the swizzle term (row>>1)&7 is the same for all of a thread's rows because RPP % 16 == 0)
-    const int row0 = tid >> 3;
-    const int chunk = GLDS ? ((tid & 7) ^ ((row0 >> 1) & 7)) : (tid & 7);
+    const int row0 = stid >> 3;
+    const int chunk = GLDS ? ((stid & 7) ^ ((row0 >> 1) & 7)) : (stid & 7);
     const int n_taps = a.kh * a.kw;
     const int nk = a.Kpad / BK;
 
@@ -180,7 +198,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
         a_off0 = ((cout0 + row0) * a.Kpad + chunk * 8) * 2;
     }
-    const int wrow = (tid >> 6) * 8;  // first row of this wave's 8-row group inside a staging pass
+    const int wrow = (stid >> 6) * 8;  // first row of this wave's 8-row group inside a staging pass
     auto dma_tile = [&](int kt, int buf) {
         typedef __attribute__((address_space(3))) void lds_void;
         char *A = smem + buf * TILE_BYTES, *B = A + CT * ROWB;
@@ -213,15 +231,24 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         }
     };
 
-    f32x16 acc[FC][FP];
+    f32x16 acc[MF ? 1 : FC][MF ? 1 : FP];
+    f32x4 acc4[MF ? 2 * FC : 1][MF ? 2 * FP : 1];
+    if constexpr (MF == 0) {
 #pragma unroll
-    for (int i = 0; i < FC; ++i)
+        for (int i = 0; i < FC; ++i)
 #pragma unroll
-        for (int j = 0; j < FP; ++j)
+            for (int j = 0; j < FP; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2 * FC; ++i)
+#pragma unroll
+            for (int j = 0; j < 2 * FP; ++j) acc4[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     const int lr = lane & 31, lh = lane >> 5;
+    const int l16 = lane & 15, lq = lane >> 4;
     // fragment read addresses: the swizzle term is the same for every fragment row of a lane (rows differ by
     // multiples of 32), so 4 bases per operand (one per k-step) + immediates cover a whole tile
     int fa_off[BK / 16], fb_off[BK / 16];
@@ -230,23 +257,111 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         fa_off[kk] = swz(wc * FC * 32 + lr, kk * 2 + lh);
         fb_off[kk] = CT * ROWB + swz(wp * FP * 32 + lr, kk * 2 + lh);
     }
-    auto compute_tile = [&](int buf) {
+    int ga_off[2], gb_off[2];  // MF 1: two K-32 steps per tile
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        ga_off[k2] = swz(wc * FC * 32 + l16, k2 * 4 + lq);
+        gb_off[k2] = CT * ROWB + swz(wp * FP * 32 + l16, k2 * 4 + lq);
+    }
+    auto compute_tile16 = [&](int buf) {
         const char *T = smem + buf * TILE_BYTES;
+        bf16x8 fa[2][2 * FC], fb[2][2 * FP];
+#pragma unroll
+        for (int i = 0; i < 2 * FC; ++i) fa[0][i] = *reinterpret_cast<const bf16x8 *>(T + ga_off[0] + i * 16 * ROWB);
+#pragma unroll
+        for (int j = 0; j < 2 * FP; ++j) fb[0][j] = *reinterpret_cast<const bf16x8 *>(T + gb_off[0] + j * 16 * ROWB);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            if (k2 == 0) {
+#pragma unroll
+                for (int i = 0; i < 2 * FC; ++i) fa[1][i] = *reinterpret_cast<const bf16x8 *>(T + ga_off[1] + i * 16 * ROWB);
+#pragma unroll
+                for (int j = 0; j < 2 * FP; ++j) fb[1][j] = *reinterpret_cast<const bf16x8 *>(T + gb_off[1] + j * 16 * ROWB);
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * FC; ++i)
+#pragma unroll
+                for (int j = 0; j < 2 * FP; ++j)
+                    acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[k2][i], fb[k2][j], acc4[i][j], 0, 0, 0);
+        }
+    };
+    auto compute_tile32 = [&](int buf) {
+        const char *T = smem + buf * TILE_BYTES;
+        // fragments of k-step kk+1 are fetched while the MFMAs of k-step kk run (two register sets)
+        bf16x8 fa[2][FC], fb[2][FP];
+#pragma unroll
+        for (int i = 0; i < FC; ++i) fa[0][i] = *reinterpret_cast<const bf16x8 *>(T + fa_off[0] + i * 32 * ROWB);
+#pragma unroll
+        for (int j = 0; j < FP; ++j) fb[0][j] = *reinterpret_cast<const bf16x8 *>(T + fb_off[0] + j * 32 * ROWB);
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 fa[FC], fb[FP];
+            if (kk + 1 < BK / 16) {
 #pragma unroll
-            for (int i = 0; i < FC; ++i) fa[i] = *reinterpret_cast<const bf16x8 *>(T + fa_off[kk] + i * 32 * ROWB);
+                for (int i = 0; i < FC; ++i) fa[(kk + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(T + fa_off[kk + 1] + i * 32 * ROWB);
 #pragma unroll
-            for (int j = 0; j < FP; ++j) fb[j] = *reinterpret_cast<const bf16x8 *>(T + fb_off[kk] + j * 32 * ROWB);
+                for (int j = 0; j < FP; ++j) fb[(kk + 1) & 1][j] = *reinterpret_cast<const bf16x8 *>(T + fb_off[kk + 1] + j * 32 * ROWB);
+            }
 #pragma unroll
             for (int i = 0; i < FC; ++i)
 #pragma unroll
                 for (int j = 0; j < FP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
         }
     };
 
+    auto compute_tile = [&](int buf) {
+        if constexpr (MF == 1) compute_tile16(buf);
+        else if constexpr (MF == 2) { /* ablation: staging only */ }
+        else compute_tile32(buf);
+    };
+
+    if constexpr (PIPE == 2) {
+        // 4-stage LDS ring (128 KiB), one workgroup per CU.  Staging waves run up to three tiles ahead of the
+        // compute waves and wait with COUNTED vmcnt (two stages may stay in flight across the barrier).
+        constexpr int NST = 4, DPS = A_ROWS + B_ROWS;  // stages; DMA instructions per stage per staging wave
+        static_assert(DPS == 8, "counted waits below assume 8 DMAs per stage");
+        if (is_loader) {
+            dma_tile(0, 0);
+            if (nk > 1) dma_tile(1, 1);
+            if (nk > 2) dma_tile(2, 2);
+            if (nk > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();  // stage 0 landed
+        for (int kt = 0; kt < nk; ++kt) {
+            if (is_loader) {
+                if (kt + 3 < nk) dma_tile(kt + 3, (kt + 3) & (NST - 1));  // refills the buffer compute(kt-1) released
+                const int ahead = min(nk - 1, kt + 3) - (kt + 1);            // stages issued beyond kt+1
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                compute_tile(kt & (NST - 1));
+            }
+            __syncthreads();  // stage kt+1 landed and published; stage kt released
+        }
+    } else if constexpr (PIPE == 1) {
+        constexpr int DMA_PER_STAGE = A_ROWS + B_ROWS;  // LDS-DMA instructions a wave issues per stage
+        static_assert(DMA_PER_STAGE == 6, "the counted wait below is written for 6 DMAs per stage");
+        const bool early = __builtin_amdgcn_readfirstlane(tid) < NT / 2;  // waves 0-3 vs their SIMD partners 4-7
+        dma_tile(0, 0);
+        if (nk > 1) dma_tile(1, 1);
+        int rd = 0, wr = 2;  // ring positions of the stage being computed / refilled
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage kt has landed when at most the NEXT stage's DMAs of this wave are still in flight
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // publishes stage kt; everyone has finished computing stage kt-1
+            const bool refill = kt + 2 < nk;
+            if (early && refill) dma_tile(kt + 2, wr);
+            compute_tile(rd);
+            if (!early && refill) dma_tile(kt + 2, wr);
+            rd = rd == 2 ? 0 : rd + 1;
+            wr = wr == 2 ? 0 : wr + 1;
+        }
+        __syncthreads();
+    } else
     if constexpr (GLDS) {
         dma_tile(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
@@ -254,7 +369,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
             // wave has finished reading the other buffer in the previous iteration -> safe to refill it
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (kt + 1 < nk) dma_tile(kt + 1, (kt + 1) & 1);
+            if (kt + 1 < nk && (MF != 3 || kt == 0)) dma_tile(kt + 1, (kt + 1) & 1);  // MF 3 = ablation: compute only
             compute_tile(kt & 1);
         }
         __syncthreads();
@@ -292,6 +407,27 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
     }
     // bias (+ReLU when no residual) -> bf16x4 -> LDS [pixel][cout] image
     char *E = smem;
+    if (is_loader) {
+        // staging waves hold no accumulators
+    } else if constexpr (MF == 1) {
+#pragma unroll
+        for (int i = 0; i < 2 * FC; ++i) {
+            const int c_local = (wc * FC * 2 + i) * 16 + 4 * lq;  // 4 consecutive couts
+            const float4 bv = *reinterpret_cast<const float4 *>(a.bias + cout0 + c_local);
+#pragma unroll
+            for (int j = 0; j < 2 * FP; ++j) {
+                const int p_local = (wp * FP * 2 + j) * 16 + l16;
+                float v0 = acc4[i][j][0] + bv.x, v1 = acc4[i][j][1] + bv.y, v2 = acc4[i][j][2] + bv.z, v3 = acc4[i][j][3] + bv.w;
+                if (a.relu && !a.res) {
+                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                }
+                uint2 pk;
+                pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+                pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
+            }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < FC; ++i) {
 #pragma unroll
@@ -337,21 +473,21 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
     }
 }
 
-template <int NT, int WC, int WP, int FC, int FP, int MODE>
+template <int NT, int WC, int WP, int FC, int FP, int MODE, int PIPE = 0, int MF = 0>
 static int launch_conv(ConvArgs &a, hipStream_t s) {
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
     a.n_ctiles = (a.Cout + CT - 1) / CT;
     a.n_ptiles = (a.M + PT - 1) / PT;
     // one staging buffer is enough when the whole K fits one tile (1x1 convs on 64 channels): more
     // workgroups per CU for the HBM-bound layers
-    const int nbuf = a.Kpad / BK > 1 ? 2 : 1;
+    const int nbuf = PIPE == 2 ? 4 : (PIPE == 1 ? 3 : (a.Kpad / BK > 1 ? 2 : 1));
     const int tile_bytes = (CT + PT) * ROWB * nbuf;
     constexpr int ep_bytes = PT * (CT * 2 + 16);
     const int lds = tile_bytes > ep_bytes ? tile_bytes : ep_bytes;
     a.pt_per_xcd = (a.n_ptiles + 7) / 8;
     const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
-    auto k = conv_igemm_kernel<NT, WC, WP, FC, FP, MODE>;
+    auto k = conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, PIPE, MF>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return MD_ERR_HIP;
@@ -435,5 +571,12 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     if (variant == 3 && !can256) variant = 2;
     if (variant == 1) return launch_conv<256, 2, 2, 2, 2, 0>(a, s);
     if (variant == 3) return fast ? launch_conv<512, 2, 4, 4, 2, 2>(a, s) : launch_conv<512, 2, 4, 4, 2, 1>(a, s);
+    if (variant == 4 && fast) return launch_conv<512, 2, 4, 2, 2, 2, 1>(a, s);  // 128(cout) x 256(pix), 3-stage ring
+    if (variant == 5 && fast) return launch_conv<256, 2, 2, 2, 2, 2, 0, 1>(a, s);  // 128x128, 16x16x32 MFMA
+    if (variant == 6 && fast) return launch_conv<256, 2, 2, 2, 2, 2, 0, 2>(a, s);  // timing ablation: staging only (wrong results)
+    if (variant == 7 && fast) return launch_conv<256, 2, 2, 2, 2, 2, 0, 3>(a, s);  // timing ablation: compute only (wrong results)
+    if (variant == 10 && fast) return launch_conv<512, 2, 2, 2, 2, 2, 2>(a, s);  // 128x128, 4 compute + 4 staging waves
+    if (variant == 8 && fast && can256) return launch_conv<512, 2, 4, 4, 2, 2, 0, 2>(a, s);  // 256x256 staging only
+    if (variant == 9 && fast && can256) return launch_conv<512, 2, 4, 4, 2, 2, 0, 3>(a, s);  // 256x256 compute only
     return fast ? launch_conv<256, 2, 2, 2, 2, 2>(a, s) : launch_conv<256, 2, 2, 2, 2, 1>(a, s);
 }

@@ -371,16 +371,23 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(const float *__restri
     const int c0 = blockIdx.x * TK_CHUNK;
     if (c0 >= n) return;
     const int c1 = min(n, c0 + TK_CHUNK);
-    // boundary bin: thread t owns bins [8t, 8t+8); suffix sums from the top
+    // boundary bin: thread t owns bins [8t, 8t+8); suffix sums from the top via a wave scan + 4 wave totals
     const unsigned *gh = ghist + (size_t)seg * TK_BINS;
     unsigned mine[8], tot = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { mine[j] = gh[tid * 8 + j]; tot += mine[j]; }
-    part[tid] = tot;
+    const int lane = tid & 63, wv = tid >> 6;
+    unsigned suf = tot;  // inclusive suffix sum inside the wave (lanes >= lane)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_down(suf, o, 64);
+        if (lane + o < 64) suf += t;
+    }
+    if (lane == 0) part[wv] = suf;  // wave total
     if (tid == 0) s_b1 = 0;
     __syncthreads();
-    unsigned above = 0;  // count in bins owned by higher threads
-    for (int t = tid + 1; t < 256; ++t) above += part[t];
+    unsigned above = suf - tot;  // bins owned by higher lanes of this wave
+    for (int w = wv + 1; w < 4; ++w) above += part[w];
     if (above < (unsigned)k && above + tot >= (unsigned)k) {
         unsigned c = above;
         int b = tid * 8 + 7;
