@@ -123,6 +123,9 @@ typedef struct md_conv2d_attrs {
      * and channel-concatenated outputs (rpn.py:152, pointpillars.py:598) run on the same MFMA kernel. */
     int32_t adv;
     int32_t pad_top, pad_left, sub_h, sub_w, out_stride, out_off_y, out_off_x, c_off, cout;
+    int32_t korder;              /* K order of the packed weights: 0 = (kh,kw,ci) [default]; 1 = (ci/64, kh,kw, ci%64)
+                                    (needs Cin % 64 == 0): taps innermost, so consecutive K tiles of a 3x3 window
+                                    re-read nearly the same activation lines */
 } md_conv2d_attrs;
 /* Replaces Conv2d -> BatchNorm2d(eval) -> [+ residual] -> ReLU of the reference graphs
  * (centernet/src/resnet.py:109-178,181-252; centerpoint/det3d_ms/models/necks/rpn.py:9-154).

@@ -52,6 +52,7 @@ struct ConvArgs {
     int Hf, Wf, Ctot;       // full output tensor dims [N,Hf,Wf,Ctot]
     int os, oy, ox, c_off;  // output pixel (ho*os + oy, wo*os + ox), channels [c_off, c_off + Cout)
     int adv;                // 0: plain (off = m*Cout + c)
+    int korder;             // 0: K = (tap, ci); 1: K = (ci/64, tap, ci%64)  (MODE 2 only)
 };
 
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((unsigned)v << 16); }
@@ -213,10 +214,16 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
                 const unsigned voff = ((p_taps[i] >> s_tap) & 1u) ? (unsigned)(p_base[i] + soff) : OOR;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(B + (wrow + RPP * i) * ROWB), 16, (int)voff, 0, 0, 0);
             }
-            s_cc0 += 8;
-            if (s_cc0 == a.cpt) {
-                s_cc0 = 0; ++s_tap;
+            if (a.korder == 0) {  // K ordered (tap, ci): channel chunks fastest
+                s_cc0 += 8;
+                if (s_cc0 == a.cpt) {
+                    s_cc0 = 0; ++s_tap;
+                    if (++s_kw == a.kw) { s_kw = 0; ++s_kh; }
+                }
+            } else {              // K ordered (ci chunk, tap, ci in chunk): taps fastest -> consecutive tiles
+                ++s_tap;          // re-read almost the same activation lines (L1/L2 reuse of the 3x3 window)
                 if (++s_kw == a.kw) { s_kw = 0; ++s_kh; }
+                if (s_tap == n_taps) { s_tap = 0; s_kh = 0; s_kw = 0; s_cc0 += 8; }
             }
         } else {
             const int tapoff = ((q_kh * a.W + q_kw) * a.Cin + q_cc * 8) * 2;
@@ -496,6 +503,206 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with HALO REUSE.
+//
+// Measured on the generic kernel (tools/conv_ab.py ablations + tools/ubench/dma_bench.hip, r01): the 128x128
+// implicit-GEMM tile is bound by L2->LDS staging (LDS-DMA tops out near 110-120 GB/s per CU), not by MFMA, and a
+// 3x3 conv stages every activation 9 times (once per tap).  Here a workgroup owns an 8x16 block of output pixels
+// of one image: per 64-channel chunk it stages the 10x18 input halo ONCE and runs all 9 taps out of it with
+// shifted fragment reads; only the 16 KiB weight slice of each (chunk, tap) step is streamed.  Staged bytes per
+// step drop from 32 KiB to 16 KiB + 23 KiB/9 = 18.6 KiB.  Weights must be packed with korder 1
+// ([Cout][ci/64][tap][64]) so that a step's slice is contiguous.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int HT_H = 8, HT_W = 16, HALO_W = HT_W + 2, HALO_ROWS = (HT_H + 2) * HALO_W;  // 180 halo pixels
+constexpr int HALO_DMAS = (HALO_ROWS + 7) / 8;                                           // 23 x 1 KiB
+constexpr int HALO_BYTES = HALO_DMAS * 1024, WSTAGE_BYTES = 128 * ROWB;
+
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int CT = 128, PT = HT_H * HT_W, FC = 2, FP = 2;
+    constexpr int EP_STRIDE = CT * 2 + 16;
+    constexpr unsigned OOR = 0x80000000u;
+    typedef __attribute__((address_space(3))) void lds_void;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *Wst = smem;                      // 2 weight stages
+    char *Hst = smem + 2 * WSTAGE_BYTES;   // 2 halo stages
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave >> 1, wp = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ct = slot % a.n_ctiles, pt = xcd * a.pt_per_xcd + slot / a.n_ctiles;
+    if (pt >= a.n_ptiles) return;
+    const int cout0 = ct * CT;
+    const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, n = pt / (tiles_x * tiles_y);
+    const int y0 = ty * HT_H, x0 = tx * HT_W;
+
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+
+    // weight staging: thread -> rows row0 + 32 i, logical chunk `chunk` (as in conv_igemm_kernel)
+    const int row0 = tid >> 3;
+    const int chunk = (tid & 7) ^ ((row0 >> 1) & 7);
+    const int a_off0 = ((cout0 + row0) * a.Kpad + chunk * 8) * 2;
+    const int wrow = wave * 8;
+    // halo staging: this wave issues DMA q = wave + 4 j (j < 6); lane -> halo row 8 q + lane/8
+    unsigned h_off[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int q = wave + 4 * j, r = q * 8 + (lane >> 3);
+        const int hy = r / HALO_W, hx = r - hy * HALO_W;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const int lchunk = (lane & 7) ^ ((r >> 1) & 7);
+        const bool ok = q < HALO_DMAS && r < HALO_ROWS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        h_off[j] = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + lchunk * 8) * 2) : OOR;
+    }
+    const int n_chunks = a.Cin / 64;
+    auto dma_weights = [&](int step, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(Wst + buf * WSTAGE_BYTES + (wrow + 32 * i) * ROWB), 16,
+                                                     a_off0 + i * (32 * a.Kpad * 2), step * (BK * 2), 0, 0);
+    };
+    auto dma_halo_piece = [&](int c, int j, int buf) {  // piece j (0..5) of chunk c's halo
+        const int q = wave + 4 * j;
+        if (q < HALO_DMAS)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(Hst + buf * HALO_BYTES + q * 1024), 16, (int)h_off[j],
+                                                     c * 128, 0, 0);
+    };
+
+    f32x16 acc[FC][FP];
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+        for (int j = 0; j < FP; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int lr = lane & 31, lh = lane >> 5;
+    int fa_off[BK / 16];
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) fa_off[kk] = swz(wc * 64 + lr, kk * 2 + lh);
+    // halo row of this lane's pixel for tap (0,0), per pixel fragment j
+    int r0[FP];
+#pragma unroll
+    for (int j = 0; j < FP; ++j) {
+        const int p = wp * 64 + j * 32 + lr;
+        r0[j] = (p >> 4) * HALO_W + (p & 15);
+    }
+
+    // prologue: halo of chunk 0 (all six pieces) + weights of step 0
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dma_halo_piece(0, j, 0);
+    dma_weights(0, 0);
+    const int n_steps = n_chunks * 9;
+    int c = 0, t = 0;  // chunk / tap of the step being computed
+    for (int s_ = 0; s_ < n_steps; ++s_) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s_ + 1 < n_steps) dma_weights(s_ + 1, (s_ + 1) & 1);
+        if (t < 6 && c + 1 < n_chunks) dma_halo_piece(c + 1, t, (c + 1) & 1);
+        // compute step (c, t): A from the weight stage, B from the halo stage at the tap's shifted rows
+        const char *Wb = Wst + (s_ & 1) * WSTAGE_BYTES;
+        const char *Hb = Hst + (c & 1) * HALO_BYTES;
+        const int radd = (t / 3) * HALO_W + (t % 3);
+        int b_off[FP];
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            const int r = r0[j] + radd, sw = (r >> 1) & 7;
+            b_off[j] = r * ROWB + (((sw & 6) | (lh ^ (sw & 1))) << 4);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 fa[FC], fb[FP];
+#pragma unroll
+            for (int i = 0; i < FC; ++i) fa[i] = *reinterpret_cast<const bf16x8 *>(Wb + fa_off[kk] + i * 32 * ROWB);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) fb[j] = *reinterpret_cast<const bf16x8 *>(Hb + (b_off[j] ^ (kk << 5)));
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int j = 0; j < FP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (++t == 9) { t = 0; ++c; }
+    }
+    __syncthreads();
+
+    // ---- epilogue (same scheme as conv_igemm_kernel): bias -> bf16x4 -> LDS [pixel][cout] -> 16-B NHWC stores
+    constexpr int CPP = CT / 8, EP_ITERS = PT * CPP / 256;
+    auto pix_off = [&](int p_local, int cglob) -> long long {
+        const int y = y0 + (p_local >> 4), x = x0 + (p_local & 15);
+        if (y >= a.H || x >= a.W || cglob >= a.Cout) return -1;
+        return ((long long)(n * a.H + y) * a.W + x) * a.Cout + cglob;
+    };
+    u32x4 rres[EP_ITERS];
+    if (a.res) {
+#pragma unroll
+        for (int it = 0; it < EP_ITERS; ++it) {
+            const int e = tid + it * 256;
+            const long long off = pix_off(e / CPP, cout0 + (e % CPP) * 8);
+            rres[it] = (u32x4){0u, 0u, 0u, 0u};
+            if (off >= 0) rres[it] = *reinterpret_cast<const u32x4 *>(a.res + off);
+        }
+    }
+    char *E = smem;
+#pragma unroll
+    for (int i = 0; i < FC; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c_local = (wc * FC + i) * 32 + 8 * g + 4 * lh;
+            const float4 bv = *reinterpret_cast<const float4 *>(a.bias + cout0 + c_local);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) {
+                const int p_local = (wp * FP + j) * 32 + lr;
+                float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
+                float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
+                if (a.relu && !a.res) {
+                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                }
+                uint2 pk;
+                pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+                pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < EP_ITERS; ++it) {
+        const int e = tid + it * 256;
+        const int p_local = e / CPP, cc = e % CPP;
+        const long long off = pix_off(p_local, cout0 + cc * 8);
+        if (off < 0) continue;
+        u32x4 v = *reinterpret_cast<const u32x4 *>(E + p_local * EP_STRIDE + cc * 16);
+        if (a.res) {
+            const u32x4 rv = rres[it];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float lo = bf2f((uint16_t)(v[k] & 0xffff)) + bf2f((uint16_t)(rv[k] & 0xffff));
+                float hi = bf2f((uint16_t)(v[k] >> 16)) + bf2f((uint16_t)(rv[k] >> 16));
+                if (a.relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                v[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+            }
+        }
+        *reinterpret_cast<u32x4 *>(a.y + off) = v;
+    }
+}
+
+static int launch_conv3x3_halo(ConvArgs &a, hipStream_t s) {
+    const int tiles_x = (a.W + HT_W - 1) / HT_W, tiles_y = (a.H + HT_H - 1) / HT_H;
+    a.n_ctiles = (a.Cout + 127) / 128;
+    a.n_ptiles = a.N * tiles_x * tiles_y;
+    a.pt_per_xcd = (a.n_ptiles + 7) / 8;
+    const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
+    if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
+    const int lds = 2 * WSTAGE_BYTES + 2 * HALO_BYTES;  // 79,872 B: two workgroups per CU
+    if (hipFuncSetAttribute((const void *)conv3x3_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return MD_ERR_HIP;
+    hipLaunchKernelGGL(conv3x3_halo_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a, tiles_x, tiles_y);
+    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
+}
+
 }  // namespace md
 
 using namespace md;
@@ -523,6 +730,7 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     a.kh = at->kh; a.kw = at->kw; a.stride = at->stride; a.pad = at->pad; a.relu = at->relu;
     if (a.kh < 1 || a.kw < 1 || a.stride < 1 || a.pad < 0) return MD_ERR_ARG;
     a.adv = at->adv != 0;
+    a.korder = at->korder;
     if (!a.adv) {
         a.Ho = a.Hf; a.Wo = a.Wf; a.Cout = a.Ctot;
         a.pad_top = a.pad_left = a.pad; a.os = 1; a.oy = a.ox = a.c_off = 0;
@@ -559,7 +767,13 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     a.x_bytes = (unsigned)(dma_ok ? x_bytes : 0);
     a.w_bytes = (unsigned)(dma_ok ? w_bytes : 0);
     if (!dma_ok) variant = 1;
+    if (a.korder != 0 && (a.korder != 1 || variant == 1 || a.Cin % 64 || a.kh * a.kw > 32)) return MD_ERR_ARG;
     const bool fast = a.Cin % 64 == 0 && a.kh * a.kw <= 32;  // MODE 2 preconditions (then Kpad == Kreal)
+    // 3x3 / stride 1 / pad 1 with korder-1 weights: halo-reuse kernel (variant 0 auto or 11 forced)
+    const bool halo_ok = dma_ok && !a.adv && a.korder == 1 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 &&
+                         a.Cin % 64 == 0 && ctile == 128;
+    if (halo_ok && (variant == 0 || variant == 11)) return launch_conv3x3_halo(a, s);
+    if (variant == 11) variant = 2;
     if (ctile != 128) {
         if (variant == 1) return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 0>(a, s) : launch_conv<256, 1, 4, 1, 2, 0>(a, s);
         if (fast) return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 2>(a, s) : launch_conv<256, 1, 4, 1, 2, 2>(a, s);

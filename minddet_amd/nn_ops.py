@@ -18,7 +18,7 @@ class _ConvAttrs(ctypes.Structure):
                 ("relu", ctypes.c_int32), ("variant", ctypes.c_int32), ("adv", ctypes.c_int32), ("pad_top", ctypes.c_int32),
                 ("pad_left", ctypes.c_int32), ("sub_h", ctypes.c_int32), ("sub_w", ctypes.c_int32),
                 ("out_stride", ctypes.c_int32), ("out_off_y", ctypes.c_int32), ("out_off_x", ctypes.c_int32),
-                ("c_off", ctypes.c_int32), ("cout", ctypes.c_int32)]
+                ("c_off", ctypes.c_int32), ("cout", ctypes.c_int32), ("korder", ctypes.c_int32)]
 
 
 def cout_tile(cout):
@@ -27,6 +27,9 @@ def cout_tile(cout):
 
 def _round_up(x, m):
     return (x + m - 1) // m * m
+
+
+KORDER_DEFAULT = 0  # K order for multi-tap convs with Cin % 64 == 0 (see md_conv2d_attrs.korder)
 
 
 class PackedConv:
@@ -47,7 +50,7 @@ class PackedConv:
     cin_real = 0
 
 
-def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, relu=False, cin_pad_to=8, cout_pad_to=8):
+def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, relu=False, cin_pad_to=8, cout_pad_to=8, korder=None):
     """weight [Cout,Cin,kh,kw] fp32 (torch, any device). bn = (gamma, beta, mean, var, eps) or None."""
     weight = weight.detach().to(torch.float32)
     cout, cin, kh, kw = weight.shape
@@ -67,12 +70,20 @@ def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, relu=False, cin_pad_t
     k_pad = _round_up(k_real, 64)
     wp = torch.zeros((cout_p, kh, kw, cin_p), dtype=torch.float32, device=weight.device)
     wp[:cout, :, :, :cin] = weight.permute(0, 2, 3, 1)
+    if korder is None:
+        # 3x3 / stride 1 / pad 1 on >= 64 channels with >= 72 output channels runs on the halo-reuse kernel, which
+        # wants the (ci/64, tap, ci%64) K order; everything else keeps (tap, ci)
+        halo = kh == 3 and kw == 3 and stride == 1 and pad == 1 and cin_p % 64 == 0 and cout_o > 64
+        korder = 1 if halo else KORDER_DEFAULT
+    if korder == 1:  # (ci/64, kh, kw, ci%64)
+        wp = wp.reshape(cout_p, kh, kw, cin_p // 64, 64).permute(0, 3, 1, 2, 4).contiguous()
     wk = torch.zeros((cout_p, k_pad), dtype=torch.float32, device=weight.device)
     wk[:, :k_real] = wp.reshape(cout_p, k_real)
     bp = torch.zeros((cout_p,), dtype=torch.float32, device=weight.device)
     bp[:cout] = b.to(weight.device)
     pc = PackedConv(wk.to(torch.bfloat16).contiguous(), bp.contiguous(), cin_p, cout_o, kh, kw, stride, pad, relu)
     pc.cin_real = cin
+    pc.korder = korder
     return pc
 
 
@@ -95,6 +106,7 @@ def conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0):
         out = torch.empty((n, ho, wo, pc.cout), dtype=torch.bfloat16, device=x.device)
     attrs = _ConvAttrs(pc.kh, pc.kw, pc.stride, pc.pad, int(pc.relu if relu is None else relu),
                        int(CONV_VARIANT if variant is None else variant))
+    attrs.korder = getattr(pc, "korder", 0)
     if out.shape[3] != pc.cout or c_off:
         attrs.adv, attrs.pad_top, attrs.pad_left, attrs.sub_h, attrs.sub_w = 1, pc.pad, pc.pad, ho, wo
         attrs.out_stride, attrs.c_off, attrs.cout = 1, int(c_off), pc.cout
@@ -148,6 +160,7 @@ def conv_transpose2d(x, pct, out=None, c_off=0):
         attrs = _ConvAttrs(pc.kh, pc.kw, 1, 0, int(pct.relu), int(CONV_VARIANT))
         attrs.adv, attrs.pad_top, attrs.pad_left, attrs.sub_h, attrs.sub_w = 1, m["pad_top"], m["pad_left"], h, w
         attrs.out_stride, attrs.out_off_y, attrs.out_off_x, attrs.c_off, attrs.cout = s, m["py"], m["px"], int(c_off), pc.cout
+        attrs.korder = getattr(pc, "korder", 0)
         _lib.call("md_conv2d", [x, pc.w, pc.bias, None, out], extra=attrs)
     return out
 

@@ -26,10 +26,13 @@ CASES = [
     ("fc_12544_1024", 1, 1, 300, 12544, 1024, 1, 1, 0, True, False, False),
     ("cout_40", 1, 20, 20, 64, 40, 3, 1, 1, True, False, True),
     ("tiny", 1, 3, 5, 8, 8, 3, 1, 1, False, False, False),
+    ("halo_ragged", 2, 13, 21, 128, 256, 3, 1, 1, True, True, True),
+    ("halo_edge", 1, 8, 16, 64, 128, 3, 1, 1, False, False, False),
+    ("halo_big", 1, 100, 168, 256, 256, 3, 1, 1, True, False, False),
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 10])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 10, 11])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_conv_vs_torch_fp32(case, variant):
     from minddet_amd import nn_ops
@@ -43,7 +46,8 @@ def test_conv_vs_torch_fp32(case, variant):
     if use_bn:
         bn = (torch.rand((Cout,), generator=g) + 0.5, torch.randn((Cout,), generator=g) * 0.1,
               torch.randn((Cout,), generator=g) * 0.1, torch.rand((Cout,), generator=g) + 0.5, 1e-5)
-    pc = nn_ops.pack_conv(w, bias=bias, bn=bn, stride=stride, pad=pad, relu=relu).to(DEV)
+    korder = 1 if (variant in (2, 5, 11) and Cin % 64 == 0 and k > 1) else 0
+    pc = nn_ops.pack_conv(w, bias=bias, bn=bn, stride=stride, pad=pad, relu=relu, korder=korder).to(DEV)
     cin_p = pc.cin
     x_nhwc = torch.zeros((N, H, W, cin_p))
     x_nhwc[..., :Cin] = x.permute(0, 2, 3, 1)
@@ -57,7 +61,10 @@ def test_conv_vs_torch_fp32(case, variant):
     y = y.float().cpu()
     # fp32 reference on the same bf16-rounded operands
     k_real = k * k * cin_p
-    wf = pc.w.float().cpu()[:Cout, :k_real].reshape(Cout, k, k, cin_p).permute(0, 3, 1, 2)
+    wf = pc.w.float().cpu()[:Cout, :k_real]
+    if pc.korder == 1:
+        wf = wf.reshape(Cout, cin_p // 64, k, k, 64).permute(0, 2, 3, 1, 4).reshape(Cout, k, k, cin_p)
+    wf = wf.reshape(Cout, k, k, cin_p).permute(0, 3, 1, 2)
     ref = F.conv2d(xb.float().permute(0, 3, 1, 2), wf, pc.bias.cpu()[:Cout], stride=stride, padding=pad)
     ref = ref.permute(0, 2, 3, 1)
     if use_res:

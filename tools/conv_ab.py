@@ -22,16 +22,21 @@ g = torch.Generator().manual_seed(0)
 rows = []
 for (H, W, Cin, Cout, k, s, res) in LAYERS:
     w = torch.randn((Cout, Cin, k, k), generator=g) * (2.0 / (k * k * Cin)) ** 0.5
-    pc = nn_ops.pack_conv(w, stride=s, pad=k // 2, relu=True).to(dev)
+    pc = nn_ops.pack_conv(w, stride=s, pad=k // 2, relu=True, korder=0).to(dev)
+    pc1 = nn_ops.pack_conv(w, stride=s, pad=k // 2, relu=True, korder=1).to(dev) if (Cin % 64 == 0 and k > 1) else None
     n = 8 if H == 1 else B
     x = torch.randn((n, H, W, pc.cin), generator=g).to(torch.bfloat16).to(dev)
     ho, wo = nn_ops.conv_out_hw(H, W, pc)
     r = torch.randn((n, ho, wo, pc.cout), generator=g).to(torch.bfloat16).to(dev) if res else None
     fl = 2.0 * n * ho * wo * Cout * Cin * k * k
-    variants = [2, 10] if nn_ops.cout_tile(pc.cout) == 128 else [1, 2]
+    variants = [2, 111] if nn_ops.cout_tile(pc.cout) == 128 else [1, 2]
     outs, times = {}, {v: [] for v in variants}
+    def run(v):
+        if v >= 100:
+            return nn_ops.conv2d(x, pc1 if pc1 is not None else pc, residual=r, variant=v - 100)
+        return nn_ops.conv2d(x, pc, residual=r, variant=v)
     for v in variants:
-        outs[v] = nn_ops.conv2d(x, pc, residual=r, variant=v)
+        outs[v] = run(v)
     torch.cuda.synchronize()
     for v in []:
         assert torch.equal(outs[v], outs[variants[0]]) or (outs[v].float() - outs[variants[0]].float()).abs().max() < 1e-1, (v, "mismatch")
@@ -40,7 +45,7 @@ for (H, W, Cin, Cout, k, s, res) in LAYERS:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
-                nn_ops.conv2d(x, pc, residual=r, variant=v)
+                run(v)
             e1.record()
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) / 3)
