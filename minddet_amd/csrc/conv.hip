@@ -92,7 +92,7 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 
 template <int NT, int WC, int WP, int FC, int FP, int MODE, int PIPE = 0, int MF = 0>
 __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr bool GLDS = MODE != 0;
-    static_assert(PIPE == 0 || (MODE == 2 && NT == 512), "the 3-stage ring is built for the LDS-DMA fast path, 8 waves");
+    static_assert(PIPE == 0 || PIPE == 3 || (MODE == 2 && NT == 512), "the ring variants are built for the LDS-DMA fast path, 8 waves");
     // PIPE 2: PRODUCER / CONSUMER waves.  Measured on the PIPE-0 kernel (tools/conv_ab.py ablations, r01): staging
     // alone takes ~60 % of the kernel time, the MFMAs alone ~35 %, and the two do not overlap -- an in-order wave
     // that is stalled issuing LDS-DMA (TA back-pressure) cannot issue its MFMAs.  Here waves [0, NT/128) only
@@ -238,6 +238,34 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         }
     };
 
+    // MODE 2 only: the same staging split into slices (one weight row group + one activation row group each), so
+    // that the DMA issue can be spread between the MFMA clusters of the tile being computed (PIPE 3).
+    auto dma_slice = [&](int kt, int buf, int q) {
+        typedef __attribute__((address_space(3))) void lds_void;
+        char *A = smem + buf * TILE_BYTES, *B = A + CT * ROWB;
+        if (q < A_ROWS)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(A + (wrow + RPP * q) * ROWB), 16,
+                                                     a_off0 + q * (RPP * a.Kpad * 2), kt * (BK * 2), 0, 0);
+        if (q < B_ROWS) {
+            const int soff = ((s_kh * a.W + s_kw) * a.Cin + s_cc0 * 8) * 2;
+            const unsigned voff = ((p_taps[q] >> s_tap) & 1u) ? (unsigned)(p_base[q] + soff) : OOR;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(B + (wrow + RPP * q) * ROWB), 16, (int)voff, 0, 0, 0);
+        }
+    };
+    auto advance_walk = [&]() {
+        if (a.korder == 0) {
+            s_cc0 += 8;
+            if (s_cc0 == a.cpt) {
+                s_cc0 = 0; ++s_tap;
+                if (++s_kw == a.kw) { s_kw = 0; ++s_kh; }
+            }
+        } else {
+            ++s_tap;
+            if (++s_kw == a.kw) { s_kw = 0; ++s_kh; }
+            if (s_tap == n_taps) { s_tap = 0; s_kh = 0; s_kw = 0; s_cc0 += 8; }
+        }
+    };
+
     f32x16 acc[MF ? 1 : FC][MF ? 1 : FP];
     f32x4 acc4[MF ? 2 * FC : 1][MF ? 2 * FP : 1];
     if constexpr (MF == 0) {
@@ -322,7 +350,51 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         else compute_tile32(buf);
     };
 
-    if constexpr (PIPE == 2) {
+    if constexpr (PIPE == 3) {
+        // Measured (r01, tools/ubench/dma_bench.hip + ablations): an LDS-DMA instruction blocks its issuing wave for
+        // ~150 cycles, and MFMAs only overlap that if they were issued BEFORE it.  So the DMAs of tile kt+1 are
+        // issued in slices right after each MFMA cluster of tile kt (the matrix pipe drains the cluster while the
+        // wave sits in the DMA issue), instead of as one burst in front of the tile.
+        static_assert(MODE == 2 && MF == 0, "interleaved issue is built on the fast path");
+        constexpr int NSL = A_ROWS > B_ROWS ? A_ROWS : B_ROWS;  // slices per tile
+        static_assert(NSL <= BK / 16 * 2, "at most two slices per k-step");
+        dma_tile(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const char *T = smem + (kt & 1) * TILE_BYTES;
+            const bool more = kt + 1 < nk;
+            const int nb = (kt + 1) & 1;
+            bf16x8 fa[2][FC], fb[2][FP];
+#pragma unroll
+            for (int i = 0; i < FC; ++i) fa[0][i] = *reinterpret_cast<const bf16x8 *>(T + fa_off[0] + i * 32 * ROWB);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) fb[0][j] = *reinterpret_cast<const bf16x8 *>(T + fb_off[0] + j * 32 * ROWB);
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                if (kk + 1 < BK / 16) {
+#pragma unroll
+                    for (int i = 0; i < FC; ++i) fa[(kk + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(T + fa_off[kk + 1] + i * 32 * ROWB);
+#pragma unroll
+                    for (int j = 0; j < FP; ++j) fb[(kk + 1) & 1][j] = *reinterpret_cast<const bf16x8 *>(T + fb_off[kk + 1] + j * 32 * ROWB);
+                }
+#pragma unroll
+                for (int i = 0; i < FC; ++i)
+#pragma unroll
+                    for (int j = 0; j < FP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    constexpr int PER = (NSL + BK / 16 - 1) / (BK / 16);
+#pragma unroll
+                    for (int q = kk * PER; q < (kk + 1) * PER && q < NSL; ++q) dma_slice(kt + 1, nb, q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) advance_walk();
+        }
+        __syncthreads();
+    } else if constexpr (PIPE == 2) {
         // 4-stage LDS ring (128 KiB), one workgroup per CU.  Staging waves run up to three tiles ahead of the
         // compute waves and wait with COUNTED vmcnt (two stages may stay in flight across the barrier).
         constexpr int NST = 4, DPS = A_ROWS + B_ROWS;  // stages; DMA instructions per stage per staging wave
@@ -689,6 +761,203 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a, int ti
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Deep-prefetch variant of the LDS-DMA fast path: K tiles of 32 channels (64-B LDS rows), a FOUR-stage ring in the
+// same 64 KiB (so still two workgroups per CU), prefetch distance three tiles, counted vmcnt.  Motivation (r01
+// measurements): a batch of LDS-DMAs takes ~1200-1500 cycles from issue to landed under load, the MFMA work of a
+// 64-deep tile is 512 cycles per wave, so with one tile of prefetch the loop is latency-bound; three tiles in
+// flight per workgroup (96 KiB per CU) cover it.  Same contract as conv_igemm_kernel MODE 2 (Cin % 64 == 0).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int RB = 32, RROWB = RB * 2;  // ring tile depth (channels) and LDS row bytes
+__device__ __forceinline__ int rswz(int row, int chunk) { return row * RROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+__global__ __launch_bounds__(256, 3) void conv_ring32_kernel(ConvArgs a) {
+    constexpr int CT = 128, PT = 128, FC = 2, FP = 2, NST = 4;
+    constexpr int STAGE_BYTES = (CT + PT) * RROWB;  // 16 KiB
+    constexpr int EP_STRIDE = CT * 2 + 16;
+    constexpr unsigned OOR = 0x80000000u;
+    typedef __attribute__((address_space(3))) void lds_void;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave >> 1, wp = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ct = slot % a.n_ctiles, pt = xcd * a.pt_per_xcd + slot / a.n_ctiles;
+    if (pt >= a.n_ptiles) return;
+    const int cout0 = ct * CT, pix0 = pt * PT;
+    const int n_taps = a.kh * a.kw;
+    const int nk = a.Kpad / RB;
+
+    // staging: one DMA = 16 rows x 64 B; wave w issues row groups w and w+4 of each operand
+    const int lrow = lane >> 2;                      // row inside the 16-row group
+    const int lchunk = (lane & 3) ^ ((lrow >> 2) & 3);  // logical 16-B chunk this lane fetches (source-side swizzle)
+    int p_base[2];
+    unsigned p_taps[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = pix0 + 16 * (wave + 4 * i) + lrow;
+        p_base[i] = 0; p_taps[i] = 0u;
+        if (m < a.M) {
+            const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
+            const int ho = r / a.Wo, wo = r - ho * a.Wo;
+            const int hi0 = ho * a.stride - a.pad_top, wi0 = wo * a.stride - a.pad_left;
+            p_base[i] = (((n * a.H + hi0) * a.W + wi0) * a.Cin + lchunk * 8) * 2;
+            unsigned bits = 0u, bit = 1u;
+            for (int dy = 0; dy < a.kh; ++dy)
+                for (int dx = 0; dx < a.kw; ++dx, bit <<= 1)
+                    if ((unsigned)(hi0 + dy) < (unsigned)a.H && (unsigned)(wi0 + dx) < (unsigned)a.W) bits |= bit;
+            p_taps[i] = bits;
+        }
+    }
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+    const int a_off0 = ((cout0 + 16 * wave + lrow) * a.Kpad + lchunk * 8) * 2;
+    int s_tap = 0, s_cc0 = 0, s_kh = 0, s_kw = 0;  // scalar K walk, 4 chunks (32 channels) per tile
+    auto dma_stage = [&](int kt, int buf) {
+        char *A = smem + buf * STAGE_BYTES, *B = A + CT * RROWB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(A + 16 * (wave + 4 * i) * RROWB), 16,
+                                                     a_off0 + i * (64 * a.Kpad * 2), kt * (RB * 2), 0, 0);
+        const int soff = ((s_kh * a.W + s_kw) * a.Cin + s_cc0 * 8) * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned voff = ((p_taps[i] >> s_tap) & 1u) ? (unsigned)(p_base[i] + soff) : OOR;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(B + 16 * (wave + 4 * i) * RROWB), 16, (int)voff, 0, 0, 0);
+        }
+        if (a.korder == 0) {
+            s_cc0 += 4;
+            if (s_cc0 == a.cpt) {
+                s_cc0 = 0; ++s_tap;
+                if (++s_kw == a.kw) { s_kw = 0; ++s_kh; }
+            }
+        } else {  // (ci/64, tap, ci%64): two 32-channel tiles per (chunk, tap)
+            s_cc0 += 4;
+            if ((s_cc0 & 7) == 0) {
+                s_cc0 -= 8; ++s_tap;
+                if (++s_kw == a.kw) { s_kw = 0; ++s_kh; }
+                if (s_tap == n_taps) { s_tap = 0; s_kh = 0; s_kw = 0; s_cc0 += 8; }
+            }
+        }
+    };
+
+    f32x16 acc[FC][FP];
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+        for (int j = 0; j < FP; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int lr = lane & 31, lh = lane >> 5;
+    int fa_off[2], fb_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        fa_off[kk] = rswz(wc * 64 + lr, kk * 2 + lh);
+        fb_off[kk] = CT * RROWB + rswz(wp * 64 + lr, kk * 2 + lh);
+    }
+
+    dma_stage(0, 0);
+    if (nk > 1) dma_stage(1, 1);
+    if (nk > 2) dma_stage(2, 2);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = min(2, nk - 1 - kt);  // stages issued after kt that may stay in flight (4 DMAs each)
+        if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // stage kt published; stage kt-1 released by every wave
+        if (kt + 3 < nk) dma_stage(kt + 3, (kt + 3) & (NST - 1));
+        const char *T = smem + (kt & (NST - 1)) * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[FC], fb[FP];
+#pragma unroll
+            for (int i = 0; i < FC; ++i) fa[i] = *reinterpret_cast<const bf16x8 *>(T + fa_off[kk] + i * 32 * RROWB);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) fb[j] = *reinterpret_cast<const bf16x8 *>(T + fb_off[kk] + j * 32 * RROWB);
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int j = 0; j < FP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue (as conv_igemm_kernel)
+    constexpr int CPP = CT / 8, EP_ITERS = PT * CPP / 256;
+    auto out_offset = [&](int m, int c) -> size_t {
+        if (!a.adv) return (size_t)m * a.Cout + c;
+        const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
+        const int ho = r / a.Wo, wo = r - ho * a.Wo;
+        return (((size_t)n * a.Hf + ho * a.os + a.oy) * a.Wf + wo * a.os + a.ox) * a.Ctot + a.c_off + c;
+    };
+    u32x4 rres[EP_ITERS];
+    if (a.res) {
+#pragma unroll
+        for (int it = 0; it < EP_ITERS; ++it) {
+            const int e = tid + it * 256;
+            const int m = pix0 + e / CPP, c = cout0 + (e % CPP) * 8;
+            rres[it] = (u32x4){0u, 0u, 0u, 0u};
+            if (m < a.M && c < a.Cout) rres[it] = *reinterpret_cast<const u32x4 *>(a.res + out_offset(m, c));
+        }
+    }
+    char *E = smem;
+#pragma unroll
+    for (int i = 0; i < FC; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c_local = (wc * FC + i) * 32 + 8 * g + 4 * lh;
+            const float4 bv = *reinterpret_cast<const float4 *>(a.bias + cout0 + c_local);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) {
+                const int p_local = (wp * FP + j) * 32 + lr;
+                float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
+                float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
+                if (a.relu && !a.res) {
+                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                }
+                uint2 pk;
+                pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+                pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < EP_ITERS; ++it) {
+        const int e = tid + it * 256;
+        const int p_local = e / CPP, cc = e % CPP;
+        const int m = pix0 + p_local, c = cout0 + cc * 8;
+        if (m >= a.M || c >= a.Cout) continue;
+        u32x4 v = *reinterpret_cast<const u32x4 *>(E + p_local * EP_STRIDE + cc * 16);
+        const size_t off = out_offset(m, c);
+        if (a.res) {
+            const u32x4 rv = rres[it];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float lo = bf2f((uint16_t)(v[k] & 0xffff)) + bf2f((uint16_t)(rv[k] & 0xffff));
+                float hi = bf2f((uint16_t)(v[k] >> 16)) + bf2f((uint16_t)(rv[k] >> 16));
+                if (a.relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                v[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+            }
+        }
+        *reinterpret_cast<u32x4 *>(a.y + off) = v;
+    }
+}
+
+static int launch_conv_ring32(ConvArgs &a, hipStream_t s) {
+    a.n_ctiles = (a.Cout + 127) / 128;
+    a.n_ptiles = (a.M + 127) / 128;
+    a.pt_per_xcd = (a.n_ptiles + 7) / 8;
+    const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
+    if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
+    const int lds = 4 * (128 + 128) * RROWB;  // 64 KiB: two workgroups per CU
+    hipLaunchKernelGGL(conv_ring32_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
+}
+
+
 static int launch_conv3x3_halo(ConvArgs &a, hipStream_t s) {
     const int tiles_x = (a.W + HT_W - 1) / HT_W, tiles_y = (a.H + HT_H - 1) / HT_H;
     a.n_ctiles = (a.Cout + 127) / 128;
@@ -774,12 +1043,15 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
                          a.Cin % 64 == 0 && ctile == 128;
     if (halo_ok && (variant == 0 || variant == 11)) return launch_conv3x3_halo(a, s);
     if (variant == 11) variant = 2;
+    if (variant == 12 && fast && ctile == 128) return launch_conv_ring32(a, s);
     if (ctile != 128) {
         if (variant == 1) return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 0>(a, s) : launch_conv<256, 1, 4, 1, 2, 0>(a, s);
         if (fast) return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 2>(a, s) : launch_conv<256, 1, 4, 1, 2, 2>(a, s);
         return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 1>(a, s) : launch_conv<256, 1, 4, 1, 2, 1>(a, s);
     }
     const bool can256 = cout_pad % 256 == 0;
+    if (variant == 13 && fast && ctile == 128) return launch_conv<256, 2, 2, 2, 2, 2, 3>(a, s);           // 128x128, interleaved DMA issue
+    if (variant == 14 && fast && ctile == 128 && can256) return launch_conv<512, 2, 4, 4, 2, 2, 3>(a, s);  // 256x256, interleaved
     if (variant == 0) variant = 2;  // measured (tools/conv_ab.py, r01): the 128x128 LDS-DMA kernel at 2 workgroups/CU beats
                                     // the 256x256 8-wave one on every benchmark layer with this one-barrier-per-tile loop
     if (variant == 3 && !can256) variant = 2;
