@@ -283,6 +283,26 @@ int md_rcnn_decode_selected(MD_AOT_ARGS);
  * out dets[B,max_det,6] f32 (x1,y1,x2,y2,score,label; zero padded), count[B] i32 */
 int md_pack_detections(MD_AOT_ARGS);
 
+/* ------------------------------------------------------------------------------------------
+ * CenterPoint head decode (centerpoint/det3d_ms/models/bbox_heads/center_head.py:297-345,398-430)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct md_centerpoint_attrs {
+    int32_t off_reg, off_height, off_dim, off_rot, off_vel /* -1: none */, off_hm, num_classes;
+    float score_threshold, out_size_factor;
+    float voxel_size[2], pc_range[2], post_center_range[6];
+} md_centerpoint_attrs;
+/* in head[B,H,W,C] bf16 (one task's attributes at the given channel offsets) ;
+ * out scores[B,HW] f32 (-1 where masked), labels[B,HW] i32 (-1), boxes[B,HW,9] f32 (x,y,z,dx,dy,dz,vx,vy,rot; 0 where
+ * masked), nms_boxes[B,HW,7] f32 (x,y,z,dy,dx,dz,-rot-pi/2 -- the operand of boxes_iou_nms_gpu, center_head.py:426-430) */
+int md_centerpoint_decode(MD_AOT_ARGS);
+/* in src[B,n,W] f32, idx[B,k] i32, cnt[B] i32 or NULL ; out out[B,k,W] f32 (zero rows past cnt) */
+int md_gather_rows(MD_AOT_ARGS);
+
+/* rotated BEV boxes -> standup (axis-aligned) boxes: pointpillars/src/core/box_np_ops.py:316-341,172-177
+ * (call site pointpillars/src/predict.py:61-78).  in boxes[N,5] (x,y,dx,dy,r) or [N,7] (x,y,z,dx,dy,dz,r) f32 ;
+ * out standup[N,4] f32 (xmin,ymin,xmax,ymax) */
+int md_standup_boxes(MD_AOT_ARGS);
+
 #ifdef __cplusplus
 }
 #endif

@@ -584,6 +584,89 @@ __global__ void centernet_assemble_kernel(const float *__restrict__ top_score, c
     out_cls[i] = cls;
 }
 
+// ------------------------------------------------------------------------------------------ CenterPoint head
+// centerpoint/det3d_ms/models/bbox_heads/center_head.py:297-345 (predict) + :398-430 (post_processing up to
+// the TopK): per BEV cell sigmoid(hm) max/argmax, exp(dim), atan2(rot), centre = (cell + reg) * out_size_factor *
+// voxel + pc_range; score/range mask -> score = label = -1, box = 0; heading flipped for the NMS operator
+// (box[:, -1] = -rot - pi/2, :426) and dims swapped in the NMS copy (:430).
+struct CpArgs {
+    int o_reg, o_height, o_dim, o_rot, o_vel, o_hm, ncls, C;
+    int H, W;
+    float score_thr, osf, vx, vy, px, py;
+    float rmin[3], rmax[3];
+};
+__global__ void centerpoint_decode_kernel(const uint16_t *__restrict__ head, CpArgs a, int total,
+                                          float *__restrict__ scores, int *__restrict__ labels,
+                                          float *__restrict__ boxes, float *__restrict__ nms_boxes) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int loc = e % (a.H * a.W);
+    const int y = loc / a.W, x = loc % a.W;
+    const uint16_t *h = head + (size_t)e * a.C;
+    float best = -FLT_MAX;
+    int lab = 0;
+    for (int c = 0; c < a.ncls; ++c) {  // ArgMaxWithValue: first maximum wins
+        const float v = 1.0f / (1.0f + expf(-rbf2f(h[a.o_hm + c])));
+        if (v > best) { best = v; lab = c; }
+    }
+    const float xs = ((float)x + rbf2f(h[a.o_reg])) * a.osf * a.vx + a.px;
+    const float ys = ((float)y + rbf2f(h[a.o_reg + 1])) * a.osf * a.vy + a.py;
+    const float zs = rbf2f(h[a.o_height]);
+    const float d0 = expf(rbf2f(h[a.o_dim])), d1 = expf(rbf2f(h[a.o_dim + 1])), d2 = expf(rbf2f(h[a.o_dim + 2]));
+    const float rot = atan2f(rbf2f(h[a.o_rot]), rbf2f(h[a.o_rot + 1]));
+    const float v0 = a.o_vel >= 0 ? rbf2f(h[a.o_vel]) : 0.f, v1 = a.o_vel >= 0 ? rbf2f(h[a.o_vel + 1]) : 0.f;
+    const bool in_range = xs >= a.rmin[0] && ys >= a.rmin[1] && zs >= a.rmin[2] && xs <= a.rmax[0] && ys <= a.rmax[1] && zs <= a.rmax[2];
+    const bool ok = best > a.score_thr && in_range;
+    float *b = boxes + (size_t)e * 9;
+    float *nb = nms_boxes + (size_t)e * 7;
+    if (ok) {
+        b[0] = xs; b[1] = ys; b[2] = zs; b[3] = d0; b[4] = d1; b[5] = d2; b[6] = v0; b[7] = v1; b[8] = rot;
+        const float r2 = -rot - 1.5707963267948966f;
+        nb[0] = xs; nb[1] = ys; nb[2] = zs; nb[3] = d1; nb[4] = d0; nb[5] = d2; nb[6] = r2;
+        scores[e] = best; labels[e] = lab;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) b[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) nb[k] = 0.f;
+        nb[6] = -1.5707963267948966f;  // -0 - pi/2, as the reference's in-place update of a zeroed row gives
+        scores[e] = -1.f; labels[e] = -1;
+    }
+}
+
+// rotated BEV box (x, y, dx, dy, r) -> axis-aligned "standup" box of its 4 corners:
+// pointpillars/src/core/box_np_ops.py:316-341 (center_to_corner_box2d, origin 0.5, corners @ [[c,-s],[s,c]])
+// + :172-177 (corner_to_standup_nd); call site pointpillars/src/predict.py:61-78.
+__global__ void standup_kernel(const float *__restrict__ boxes, int n, int stride, int ix, int iy, int idx_, int idy, int ir,
+                               float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *b = boxes + (size_t)i * stride;
+    const float cx = b[ix], cy = b[iy], dx = b[idx_], dy = b[idy], r = b[ir];
+    const float s = sinf(r), c = cosf(r);
+    const float nx[4] = {-0.5f, -0.5f, 0.5f, 0.5f}, ny[4] = {-0.5f, 0.5f, 0.5f, -0.5f};
+    float x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float px = dx * nx[k], py = dy * ny[k];
+        const float qx = px * c + py * s + cx, qy = -px * s + py * c + cy;
+        if (k == 0) { x0 = x1 = qx; y0 = y1 = qy; }
+        else { x0 = fminf(x0, qx); x1 = fmaxf(x1, qx); y0 = fminf(y0, qy); y1 = fmaxf(y1, qy); }
+    }
+    *reinterpret_cast<float4 *>(out + (size_t)i * 4) = make_float4(x0, y0, x1, y1);
+}
+
+// out[b, j, :] = src[b, idx[b, j], :] for j < cnt[b] (zero rows past cnt); W floats per row
+__global__ void gather_rows_kernel(const float *__restrict__ src, const int *__restrict__ idx, const int *__restrict__ cnt,
+                                   int B, int n_src, int k, int W, float *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * k * W) return;
+    const int w = e % W, j = (e / W) % k, b = e / (W * k);
+    float v = 0.f;
+    if (!cnt || j < cnt[b]) v = src[((size_t)b * n_src + idx[(size_t)b * k + j]) * W + w];
+    out[e] = v;
+}
+
 __global__ void sigmoid_clip_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n, float lo, float hi) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const float s = 1.0f / (1.0f + expf(-x[e]));
@@ -818,6 +901,74 @@ extern "C" int md_centernet_assemble(MD_AOT_ARGS) {
     hipLaunchKernelGGL(centernet_assemble_kernel, dim3((B * K + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        (const float *)params[0], (const int *)params[1], (const int *)params[2], (const float *)params[3],
                        (const float *)params[4], B, C, K, H, W, (float *)params[5], (int *)params[6], (int *)params[7]);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+
+extern "C" int md_centerpoint_decode(MD_AOT_ARGS) {
+    // in: head[B,H,W,C] bf16 ; out: scores[B,HW] f32, labels[B,HW] i32, boxes[B,HW,9] f32, nms_boxes[B,HW,7] f32
+    if (nparam != 5) return MD_ERR_NPARAM;
+    if (!params || !extra || !ndims || ndims[0] != 4) return MD_ERR_ARG;
+    if (!dtype_is(dtypes, 0, "bfloat16") || !dtype_is(dtypes, 1, "float32") || !dtype_is(dtypes, 2, "int32") ||
+        !dtype_is(dtypes, 3, "float32") || !dtype_is(dtypes, 4, "float32"))
+        return MD_ERR_ARG;
+    const md_centerpoint_attrs *at = (const md_centerpoint_attrs *)extra;
+    CpArgs a;
+    a.o_reg = at->off_reg; a.o_height = at->off_height; a.o_dim = at->off_dim; a.o_rot = at->off_rot;
+    a.o_vel = at->off_vel; a.o_hm = at->off_hm; a.ncls = at->num_classes;
+    const int B = (int)shapes[0][0];
+    a.H = (int)shapes[0][1]; a.W = (int)shapes[0][2]; a.C = (int)shapes[0][3];
+    if (a.ncls < 1 || a.o_hm + a.ncls > a.C || a.o_reg + 2 > a.C || a.o_dim + 3 > a.C || a.o_rot + 2 > a.C ||
+        a.o_height + 1 > a.C || a.o_vel + 2 > a.C)
+        return MD_ERR_ARG;
+    a.score_thr = at->score_threshold; a.osf = at->out_size_factor; a.vx = at->voxel_size[0]; a.vy = at->voxel_size[1];
+    a.px = at->pc_range[0]; a.py = at->pc_range[1];
+    for (int i = 0; i < 3; ++i) { a.rmin[i] = at->post_center_range[i]; a.rmax[i] = at->post_center_range[3 + i]; }
+    const int64_t total = (int64_t)B * a.H * a.W;
+    if (numel(ndims, shapes, 1) != total || numel(ndims, shapes, 2) != total || numel(ndims, shapes, 3) != total * 9 ||
+        numel(ndims, shapes, 4) != total * 7)
+        return MD_ERR_ARG;
+    if (total == 0) return MD_OK;
+    if (total > 0x7fffffffLL) return MD_ERR_SIZE;
+    hipLaunchKernelGGL(centerpoint_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)params[0], a, (int)total, (float *)params[1], (int *)params[2], (float *)params[3],
+                       (float *)params[4]);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+
+extern "C" int md_standup_boxes(MD_AOT_ARGS) {
+    // in: boxes[N, S] f32 (S = 5: x,y,dx,dy,r ; S = 7: x,y,z,dx,dy,dz,r) ; out: standup[N,4] f32
+    if (nparam != 2) return MD_ERR_NPARAM;
+    if (!params || !ndims || ndims[0] != 2 || !dtype_is(dtypes, 0, "float32") || !dtype_is(dtypes, 1, "float32")) return MD_ERR_ARG;
+    const int64_t n = shapes[0][0];
+    const int S = (int)shapes[0][1];
+    if ((S != 5 && S != 7) || numel(ndims, shapes, 1) != n * 4) return MD_ERR_ARG;
+    if (n == 0) return MD_OK;
+    if (n > 0x7fffffffLL) return MD_ERR_SIZE;
+    if (S == 5)
+        hipLaunchKernelGGL(standup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)params[0], (int)n, 5, 0, 1, 2, 3, 4, (float *)params[1]);
+    else
+        hipLaunchKernelGGL(standup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)params[0], (int)n, 7, 0, 1, 3, 4, 6, (float *)params[1]);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+
+extern "C" int md_gather_rows(MD_AOT_ARGS) {
+    // in: src[B,n,W] f32, idx[B,k] i32, cnt[B] i32 or NULL ; out: out[B,k,W] f32
+    if (nparam != 4) return MD_ERR_NPARAM;
+    if (!params || !ndims || ndims[0] != 3 || ndims[1] != 2) return MD_ERR_ARG;
+    if (!dtype_is(dtypes, 0, "float32") || !dtype_is(dtypes, 1, "int32") || !dtype_is(dtypes, 2, "int32") ||
+        !dtype_is(dtypes, 3, "float32"))
+        return MD_ERR_ARG;
+    const int B = (int)shapes[0][0], n = (int)shapes[0][1], W = (int)shapes[0][2], k = (int)shapes[1][1];
+    if (shapes[1][0] != B || numel(ndims, shapes, 3) != (int64_t)B * k * W) return MD_ERR_ARG;
+    if ((int64_t)B * k * W == 0) return MD_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(((int64_t)B * k * W + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float *)params[0], (const int *)params[1], (const int *)params[2], B, n, k,
+                       W, (float *)params[3]);
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }

@@ -465,3 +465,107 @@ def pack_detections(boxes, scores, labels, keep_idx, num, max_det):
     count = torch.empty((B,), dtype=torch.int32, device=boxes.device)
     _lib.call("md_pack_detections", [boxes, scores, labels, keep_idx, num, dets, count])
     return dets, count
+
+
+# ----------------------------------------------------------------------------- CenterPoint head post-processing
+class _CenterPointAttrs(ctypes.Structure):
+    _fields_ = [("off_reg", ctypes.c_int32), ("off_height", ctypes.c_int32), ("off_dim", ctypes.c_int32),
+                ("off_rot", ctypes.c_int32), ("off_vel", ctypes.c_int32), ("off_hm", ctypes.c_int32),
+                ("num_classes", ctypes.c_int32), ("score_threshold", ctypes.c_float), ("out_size_factor", ctypes.c_float),
+                ("voxel_size", ctypes.c_float * 2), ("pc_range", ctypes.c_float * 2), ("post_center_range", ctypes.c_float * 6)]
+
+
+def gather_rows(src, idx, cnt=None):
+    """src [B,n,W] f32, idx [B,k] i32 -> [B,k,W] (zero rows past cnt)."""
+    B, k = idx.shape
+    out = torch.empty((B, k, src.shape[2]), dtype=torch.float32, device=src.device)
+    _lib.call("md_gather_rows", [src, idx, cnt, out])
+    return out
+
+
+class CenterHeadPost:
+    """Mirror of CenterHead.predict + post_processing for ONE task
+    (centerpoint/det3d_ms/models/bbox_heads/center_head.py:273-463): decode every BEV cell, mask by score and
+    post_center_range, TopK(nms_pre_max_size), rotated NMS through the AOT operator's device twin
+    (`self.nms(boxes_for_nms_sorted, thr)`, :443-445), count = min(num_out, mask_num, nms_post_max_size)."""
+
+    def __init__(self, offsets, num_classes, test_cfg):
+        self.off, self.nc, self.cfg = dict(offsets), int(num_classes), test_cfg
+
+    def __call__(self, head, return_aux=False):
+        B, H, W, C = head.shape
+        cfg = self.cfg
+        at = _CenterPointAttrs()
+        at.off_reg, at.off_height, at.off_dim, at.off_rot = self.off["reg"], self.off["height"], self.off["dim"], self.off["rot"]
+        at.off_vel, at.off_hm, at.num_classes = self.off.get("vel", -1), self.off["hm"], self.nc
+        at.score_threshold, at.out_size_factor = float(cfg["score_threshold"]), float(cfg["out_size_factor"])
+        for i in range(2):
+            at.voxel_size[i], at.pc_range[i] = float(cfg["voxel_size"][i]), float(cfg["pc_range"][i])
+        for i in range(6):
+            at.post_center_range[i] = float(cfg["post_center_limit_range"][i])
+        dev = head.device
+        n = H * W
+        scores = torch.empty((B, n), dtype=torch.float32, device=dev)
+        labels = torch.empty((B, n), dtype=torch.int32, device=dev)
+        boxes = torch.empty((B, n, 9), dtype=torch.float32, device=dev)
+        nms_boxes = torch.empty((B, n, 7), dtype=torch.float32, device=dev)
+        _lib.call("md_centerpoint_decode", [head, scores, labels, boxes, nms_boxes], extra=at)
+        k = int(cfg["nms"]["nms_pre_max_size"])
+        sc_sorted, order = top_k(scores, k)                       # TopK over ALL cells, masked ones carry -1 (:435)
+        nb_sorted = gather_rows(nms_boxes, order)
+        bx_sorted = gather_rows(boxes, order)
+        mask_num = (sc_sorted > -1.0).sum(1).to(torch.int32)      # == mask[order].sum() (:439-441)
+        nms = NMS()
+        keeps, nums = [], []
+        for b in range(B):                                       # the reference loops the batch too (:405)
+            kp, nm = nms(nb_sorted[b], cfg["nms"]["nms_iou_threshold"])
+            keeps.append(kp)
+            nums.append(nm.reshape(1))
+        keep = torch.stack(keeps)
+        num_out = torch.cat(nums)
+        count = torch.minimum(torch.minimum(num_out, mask_num), torch.full_like(num_out, int(cfg["nms"]["nms_post_max_size"])))
+        sel_boxes = gather_rows(bx_sorted, keep)
+        sel_scores = torch.gather(sc_sorted, 1, keep.long())
+        sel_labels = torch.gather(torch.gather(labels, 1, order.long()), 1, keep.long())
+        out = [sel_boxes, sel_scores, sel_labels, count]
+        if return_aux:
+            return out, dict(scores=scores, labels=labels, boxes=boxes, nms_boxes=nms_boxes, order=order, keep=keep,
+                             num_out=num_out, mask_num=mask_num)
+        return out
+
+
+# ----------------------------------------------------------------------------- PointPillars host post-process
+def _just_below(x):
+    """Largest float32 strictly below x: `score >= x` (predict.py:30) expressed as `score > just_below(x)`."""
+    import numpy as np
+
+    return float(np.nextafter(np.float32(x), np.float32(-np.inf)))
+
+
+def standup_boxes(boxes):
+    """Rotated BEV boxes [N,5] (x,y,dx,dy,r) or [N,7] -> standup boxes [N,4] (predict.py:61-78)."""
+    b = _f32c(boxes)
+    out = torch.empty((b.shape[0], 4), dtype=torch.float32, device=b.device)
+    _lib.call("md_standup_boxes", [b, out])
+    return out
+
+
+def pp_get_selected_data(total_scores, box_preds, anchors_mask, cfg):
+    """Mirror of PointPillarsNet.get_selected_data (pointpillars/src/pointpillars.py:753-765) followed by the host
+    post-process _get_selected_data (pointpillars/src/predict.py:43-98) for one sample, on device:
+    class max / argmax, anchor-mask -> -1, top_k(nms_pre_max_size), score threshold, standup boxes, NMS on the
+    standup boxes (nms_jit convention: the reference's ops.NMSWithMask arithmetic is not in the repository),
+    first nms_post_max_size survivors.  Returns (boxes[K,7], scores[K], labels[K], count)."""
+    top_scores, top_labels = total_scores.max(-1)
+    top_scores = torch.where(anchors_mask, top_scores, torch.full_like(top_scores, -1.0))
+    k = min(int(cfg["nms_pre_max_size"]), top_scores.numel())
+    vals, idx, cnt = topk_segmented(top_scores, torch.tensor([0, top_scores.numel()], dtype=torch.int32, device=top_scores.device),
+                                    k, min_score=_just_below(cfg["nms_score_threshold"]) if cfg["nms_score_threshold"] > 0 else None,
+                                    max_segment=top_scores.numel())
+    sel = gather_rows(_f32c(box_preds).unsqueeze(0), idx, cnt)[0]      # [k,7], zero rows past cnt
+    st = standup_boxes(sel)
+    mask, kidx, num = nms_aligned(st.unsqueeze(0), float(cfg["nms_iou_threshold"]), 0.0, NMS_MODE_JIT, count=cnt,
+                                  max_output=int(cfg["nms_post_max_size"]))
+    n = num[0]
+    ki = kidx[0].long()
+    return sel[ki], vals[0][ki], top_labels[idx[0].long()][ki], n

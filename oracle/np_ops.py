@@ -503,3 +503,32 @@ def roi_align_fast(feat, rois, out_size, spatial_scale, sampling_ratio=2, aligne
                 acc += np.where(oob[..., None], np.float32(0), v)
         out[r0:r0 + n] = (acc / np.float32(g * g)).transpose(0, 3, 1, 2)
     return out
+
+
+# ----------------------------------------------------------------------------- CenterPoint head
+def centerpoint_decode(head, off, ncls, cfg):
+    """CP/det3d_ms/models/bbox_heads/center_head.py:297-345 + :398-430 for one task.
+    head [B,H,W,C] float32 (attributes at channel offsets `off`).  Returns scores [B,HW] (-1 masked),
+    labels [B,HW] (-1), boxes [B,HW,9], nms_boxes [B,HW,7] (dims swapped, heading -rot - pi/2)."""
+    B, H, W, _ = head.shape
+    f = head.reshape(B, H * W, -1).astype(np.float32)
+    hm = (1.0 / (1.0 + np.exp(-f[..., off["hm"]:off["hm"] + ncls]))).astype(np.float32)
+    labels = hm.argmax(-1).astype(np.int32)
+    scores = hm.max(-1)
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    xs = (xs.reshape(1, -1) + f[..., off["reg"]]) * np.float32(cfg["out_size_factor"]) * np.float32(cfg["voxel_size"][0]) + np.float32(cfg["pc_range"][0])
+    ys = (ys.reshape(1, -1) + f[..., off["reg"] + 1]) * np.float32(cfg["out_size_factor"]) * np.float32(cfg["voxel_size"][1]) + np.float32(cfg["pc_range"][1])
+    zs = f[..., off["height"]]
+    dim = np.exp(f[..., off["dim"]:off["dim"] + 3])
+    rot = np.arctan2(f[..., off["rot"]], f[..., off["rot"] + 1])
+    vel = f[..., off["vel"]:off["vel"] + 2] if off.get("vel", -1) >= 0 else np.zeros((B, H * W, 2), np.float32)
+    boxes = np.concatenate([xs[..., None], ys[..., None], zs[..., None], dim, vel, rot[..., None]], -1).astype(np.float32)
+    r = np.asarray(cfg["post_center_limit_range"], np.float32)
+    mask = (scores > np.float32(cfg["score_threshold"])) & (boxes[..., :3] >= r[:3]).all(-1) & (boxes[..., :3] <= r[3:]).all(-1)
+    scores = np.where(mask, scores, np.float32(-1))
+    labels = np.where(mask, labels, -1).astype(np.int32)
+    boxes = np.where(mask[..., None], boxes, np.float32(0))
+    flipped = boxes.copy()
+    flipped[..., -1] = -flipped[..., -1] - np.float32(np.pi / 2)
+    nms_boxes = flipped[..., [0, 1, 2, 4, 3, 5, -1]]
+    return scores, labels, boxes, nms_boxes, mask

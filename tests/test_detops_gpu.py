@@ -218,3 +218,45 @@ def test_maxpool_upsample_slice():
     assert torch.equal(y, (x.float() + up).to(torch.bfloat16).float())
     s = nn_ops.slice_cast(x.to(DEV), 5, 12).cpu()
     assert torch.equal(s, x.float()[..., 5:17])
+
+
+def test_standup_boxes_golden(golden):
+    from minddet_amd import det_ops
+
+    rb = golden["near_in"]
+    got = det_ops.standup_boxes(T(rb)).cpu().numpy()
+    np.testing.assert_allclose(got, golden["standup_out"], rtol=0, atol=2e-5)   # the reference's own output
+    b7 = np.zeros((rb.shape[0], 7), np.float32)
+    b7[:, [0, 1, 3, 4, 6]] = rb
+    np.testing.assert_allclose(det_ops.standup_boxes(T(b7)).cpu().numpy(), golden["standup_out"], rtol=0, atol=2e-5)
+
+
+def test_pp_selected_data_flow():
+    """pointpillars.py:753-765 + predict.py:43-98 on device vs numpy (car config: pre 900? uses 1000 here, post 300)."""
+    from minddet_amd import det_ops
+    import oracle
+
+    rng = np.random.default_rng(5)
+    n = 107136
+    scores = (1 / (1 + np.exp(-rng.normal(-4, 2, (n, 1))))).astype(np.float32)
+    boxes = np.concatenate([rng.uniform(0, 69, (n, 1)), rng.uniform(-39, 39, (n, 1)), rng.uniform(-2, 0, (n, 1)),
+                            rng.uniform(1.4, 1.8, (n, 1)), rng.uniform(3.5, 4.5, (n, 1)), rng.uniform(1.4, 1.7, (n, 1)),
+                            rng.uniform(-3.14, 3.14, (n, 1))], 1).astype(np.float32)
+    amask = rng.uniform(0, 1, n) < 0.4
+    cfg = dict(nms_pre_max_size=1000, nms_post_max_size=300, nms_iou_threshold=0.01, nms_score_threshold=0.05)
+    b, s, l, cnt = det_ops.pp_get_selected_data(T(scores), T(boxes), T(amask), cfg)
+    cnt = int(cnt)
+    top = np.where(amask, scores[:, 0], np.float32(-1))
+    keepable = top >= np.float32(0.05)
+    v, i = np_ops.topk_desc_stable(np.where(keepable, top, -np.inf), 1000)
+    m = min(1000, int(keepable.sum()))
+    v, i = v[:m], i[:m]
+    st = np_ops.corner_to_standup_nd(np_ops.center_to_corner_box2d(boxes[i][:, :2], boxes[i][:, 3:5], boxes[i][:, 6]))
+    st_dev = det_ops.standup_boxes(T(boxes[i])).cpu().numpy()
+    np.testing.assert_allclose(st_dev, st, atol=2e-5)
+    keep = oracle.nms_aligned(st_dev, 0.01, 0.0, 0).astype(bool)   # NMS from the device standup boxes: exact
+    kidx = np.nonzero(keep)[0][:300]
+    assert cnt == len(kidx)
+    np.testing.assert_array_equal(s.cpu().numpy()[:cnt], v[kidx])
+    np.testing.assert_array_equal(b.cpu().numpy()[:cnt], boxes[i][kidx])
+    assert (l.cpu().numpy()[:cnt] == 0).all()
