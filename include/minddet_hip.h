@@ -102,6 +102,16 @@ typedef struct md_nms_attrs {
  * extra: md_nms_attrs (required). */
 int md_nms_aligned(MD_AOT_ARGS);
 
+typedef struct md_soft_nms_attrs {
+    float sigma, Nt, threshold; /* reference call: sigma 0.5 (default), Nt 0.5, threshold 0.001 */
+    int32_t method;             /* 1 linear, 2 gaussian, 3 hard */
+} md_soft_nms_attrs;
+/* Soft-NMS (Bodla et al. 2017; call site centernet/src/post_process.py:45-52 -- the Cython module is not vendored in
+ * the reference, parity unpinned).  in boxes[L,N,4] f32, scores[L,N] f32, count[L] i32 or NULL (N <= 1024) ;
+ * out scores_out[L,N] f32 (decayed score of each surviving box at its ORIGINAL position, 0 = removed),
+ * order[L,N] i32 (survivors in selection order, leading num valid), num[L] i32 */
+int md_soft_nms(MD_AOT_ARGS);
+
 /* circle_nms (centerpoint/det3d_ms/core/utils/circle_nms_jit.py:6-36):
  * in xy[N,2] f32 sorted by score desc, thresh[1] f32 ; out keep_mask[N] u8, keep_idx[N] i32,
  * num[1] i32.  Suppress iff squared centre distance <= thresh. */

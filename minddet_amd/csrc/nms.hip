@@ -210,6 +210,84 @@ __global__ __launch_bounds__(256) void circle_mask_kernel(const float *__restric
     }
 }
 
+// ------------------------------------------------------------------ soft-NMS
+// Soft-NMS (Bodla et al. 2017) as used by the reference through the un-vendored CenterNet Cython module
+// (call site centernet/src/post_process.py:45-52: method 2 = gaussian, Nt 0.5, threshold 0.001, sigma 0.5, +1 pixel
+// areas).  One wave per list (<= 1024 boxes, CenterNet has <= 100 per class): pick the best live box, decay every
+// other live box by its overlap with it, drop those whose score falls below the threshold, repeat.
+// method: 1 linear, 2 gaussian, 3 hard (weight 0 above Nt).
+__global__ __launch_bounds__(64) void soft_nms_kernel(const float *__restrict__ boxes_all, const float *__restrict__ scores_all,
+                                                       const int *__restrict__ count, int n_max, float sigma, float Nt,
+                                                       float threshold, int method, float *__restrict__ out_scores_all,
+                                                       int *__restrict__ order_all, int *__restrict__ num_all) {
+    constexpr int PER = 16;  // boxes per lane -> up to 1024 per list
+    const int list = blockIdx.x, lane = threadIdx.x;
+    const int n = count ? min(count[list], n_max) : n_max;
+    const float *boxes = boxes_all + (size_t)list * n_max * 4;
+    float x1[PER], y1[PER], x2[PER], y2[PER], sc[PER];
+    int state[PER];  // 0 live, 1 selected, 2 removed / absent
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int i = lane + 64 * t;
+        state[t] = 2; sc[t] = 0.f; x1[t] = y1[t] = x2[t] = y2[t] = 0.f;
+        if (i < n) {
+            const float4 b = *reinterpret_cast<const float4 *>(boxes + (size_t)i * 4);
+            x1[t] = b.x; y1[t] = b.y; x2[t] = b.z; y2[t] = b.w;
+            sc[t] = scores_all[(size_t)list * n_max + i];
+            state[t] = 0;
+        }
+    }
+    int picked = 0;
+    for (int it = 0; it < n; ++it) {
+        // arg-max over live boxes (ties -> lowest index)
+        float best = -3.0e38f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int t = 0; t < PER; ++t)
+            if (state[t] == 0 && (sc[t] > best)) { best = sc[t]; bi = lane + 64 * t; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (bi == 0x7fffffff) break;  // nothing live (wave-uniform)
+        const int owner = bi & 63, slot = bi >> 6;
+        float tx1 = 0, ty1 = 0, tx2 = 0, ty2 = 0;
+#pragma unroll
+        for (int t = 0; t < PER; ++t)
+            if (t == slot) { tx1 = x1[t]; ty1 = y1[t]; tx2 = x2[t]; ty2 = y2[t]; if (lane == owner) state[t] = 1; }
+        tx1 = __shfl(tx1, owner, 64); ty1 = __shfl(ty1, owner, 64); tx2 = __shfl(tx2, owner, 64); ty2 = __shfl(ty2, owner, 64);
+        if (lane == 0) order_all[(size_t)list * n_max + picked] = bi;
+        ++picked;
+        const float tarea = (tx2 - tx1 + 1.f) * (ty2 - ty1 + 1.f);
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            if (state[t] != 0) continue;
+            const float iw = fminf(tx2, x2[t]) - fmaxf(tx1, x1[t]) + 1.f;
+            if (iw > 0.f) {
+                const float ih = fminf(ty2, y2[t]) - fmaxf(ty1, y1[t]) + 1.f;
+                if (ih > 0.f) {
+                    const float area = (x2[t] - x1[t] + 1.f) * (y2[t] - y1[t] + 1.f);
+                    const float ov = iw * ih / (tarea + area - iw * ih);
+                    float w = 1.f;
+                    if (method == 1) w = ov > Nt ? 1.f - ov : 1.f;
+                    else if (method == 2) w = expf(-(ov * ov) / sigma);
+                    else w = ov > Nt ? 0.f : 1.f;
+                    sc[t] = w * sc[t];
+                    if (sc[t] < threshold) state[t] = 2;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int i = lane + 64 * t;
+        if (i < n_max) out_scores_all[(size_t)list * n_max + i] = state[t] == 1 ? sc[t] : 0.f;
+    }
+    for (int i = picked + lane; i < n_max; i += 64) order_all[(size_t)list * n_max + i] = 0;
+    if (lane == 0) num_all[list] = picked;
+}
+
 // ------------------------------------------------------------------ on-device greedy pass
 __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
     const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v);
@@ -485,6 +563,31 @@ extern "C" int md_nms_aligned(MD_AOT_ARGS) {
     hipLaunchKernelGGL((nms_scan_kernel<int>), dim3((unsigned)B), dim3(256), scan_lds(cb), s, mask,
                        (const int *)params[1], (int)n, cb, (const float *)nullptr, 0, at->max_output, (int *)params[4],
                        (int *)params[5], (unsigned char *)params[3]);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+
+extern "C" int md_soft_nms(MD_AOT_ARGS) {
+    // in: boxes[L,N,4] f32 (or [N,4]), scores[L,N] f32, count[L] i32 | NULL ; out: scores_out[L,N] f32 (0 = removed),
+    //     order[L,N] i32 (selection order, leading num valid), num[L] i32.  extra: md_soft_nms_attrs
+    if (nparam != 6) return MD_ERR_NPARAM;
+    if (!params || !extra || !ndims) return MD_ERR_ARG;
+    if (!dtype_is(dtypes, 0, "float32") || !dtype_is(dtypes, 1, "float32") || !dtype_is(dtypes, 2, "int32") ||
+        !dtype_is(dtypes, 3, "float32") || !dtype_is(dtypes, 4, "int32") || !dtype_is(dtypes, 5, "int32"))
+        return MD_ERR_ARG;
+    const int nd = ndims[0];
+    if (nd != 2 && nd != 3) return MD_ERR_ARG;
+    const int64_t L = nd == 3 ? shapes[0][0] : 1, n = shapes[0][nd - 2];
+    if (shapes[0][nd - 1] != 4 || numel(ndims, shapes, 1) != L * n || numel(ndims, shapes, 3) != L * n ||
+        numel(ndims, shapes, 4) != L * n || numel(ndims, shapes, 5) != L)
+        return MD_ERR_ARG;
+    if (n > 1024) return MD_ERR_SIZE;
+    const md_soft_nms_attrs *at = (const md_soft_nms_attrs *)extra;
+    if (at->method < 1 || at->method > 3 || !(at->sigma > 0.f)) return MD_ERR_ARG;
+    if (L == 0) return MD_OK;
+    hipLaunchKernelGGL(soft_nms_kernel, dim3((unsigned)L), dim3(64), 0, (hipStream_t)stream, (const float *)params[0],
+                       (const float *)params[1], (const int *)params[2], (int)n, at->sigma, at->Nt, at->threshold, at->method,
+                       (float *)params[3], (int *)params[4], (int *)params[5]);
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }

@@ -569,3 +569,77 @@ def pp_get_selected_data(total_scores, box_preds, anchors_mask, cfg):
     n = num[0]
     ki = kidx[0].long()
     return sel[ki], vals[0][ki], top_labels[idx[0].long()][ki], n
+
+
+# ----------------------------------------------------------------------------- CenterNet post-process (post_process.py)
+class _SoftNmsAttrs(ctypes.Structure):
+    _fields_ = [("sigma", ctypes.c_float), ("Nt", ctypes.c_float), ("threshold", ctypes.c_float), ("method", ctypes.c_int32)]
+
+
+def soft_nms(boxes, scores, count=None, sigma=0.5, Nt=0.5, threshold=0.001, method=2):
+    """boxes [L,N,4] / [N,4], scores [L,N] / [N] -> (scores_out, order, num). See md_soft_nms."""
+    b, s = _f32c(boxes), _f32c(scores)
+    batched = b.dim() == 3
+    L, n = (b.shape[0], b.shape[1]) if batched else (1, b.shape[0])
+    so = torch.empty((L, n), dtype=torch.float32, device=b.device)
+    order = torch.empty((L, n), dtype=torch.int32, device=b.device)
+    num = torch.empty((L,), dtype=torch.int32, device=b.device)
+    _lib.call("md_soft_nms", [b.view(L, n, 4), s.view(L, n), count, so, order, num], extra=_SoftNmsAttrs(sigma, Nt, threshold, method))
+    return (so, order, num) if batched else (so[0], order[0], num)
+
+
+def get_affine_transform(center, scale, output_size, inv=True):
+    """centernet/src/image.py (get_affine_transform with rot = 0): the 2x3 matrix cv2.getAffineTransform returns for
+    the three reference points, solved here in float64 (cv2 is not a dependency)."""
+    import numpy as np
+
+    scale = np.array([scale, scale], np.float32) if np.isscalar(scale) else np.asarray(scale, np.float32)
+    src_w, dst_w, dst_h = scale[0], output_size[0], output_size[1]
+    center = np.asarray(center, np.float32)
+    src = np.zeros((3, 2), np.float32)
+    dst = np.zeros((3, 2), np.float32)
+    src[0] = center
+    src[1] = center + np.array([0, src_w * -0.5], np.float32)
+    dst[0] = [dst_w * 0.5, dst_h * 0.5]
+    dst[1] = np.array([dst_w * 0.5, dst_h * 0.5], np.float32) + np.array([0, dst_w * -0.5], np.float32)
+    for p in (src, dst):
+        d = p[0] - p[1]
+        p[2] = p[1] + np.array([-d[1], d[0]], np.float32)
+    a, b = (dst, src) if inv else (src, dst)
+    A = np.concatenate([a.astype(np.float64), np.ones((3, 1))], 1)
+    return np.linalg.solve(A, b.astype(np.float64)).T  # [2,3]
+
+
+def centernet_post_process(dets, c, s, out_hw, scale, num_classes, soft=True, max_per_image=100):
+    """Mirror of post_process + merge_outputs (centernet/src/post_process.py:10-61) for one image, on device.
+    dets [K,6] (x1,y1,x2,y2,score,cls) in feature-map units -> rows surviving the per-class (soft-)NMS and the
+    global top-max_per_image cut, in image coordinates: (boxes [M,4], scores [M], classes [M])."""
+    t = torch.from_numpy(get_affine_transform(c, s, (out_hw[1], out_hw[0]))).to(dets.device)
+    d = dets.to(torch.float64)
+    xy1 = (d[:, 0:2] @ t[:, :2].T + t[:, 2]).to(torch.float32) / scale
+    xy2 = (d[:, 2:4] @ t[:, :2].T + t[:, 2]).to(torch.float32) / scale
+    boxes = torch.cat([xy1, xy2], 1).contiguous()
+    scores, cls = dets[:, 4].contiguous(), dets[:, 5].to(torch.int32)
+    K = boxes.shape[0]
+    if soft:
+        # per-class lists: class-major padding [C, K]
+        lists_b = torch.zeros((num_classes, K, 4), dtype=torch.float32, device=dets.device)
+        lists_s = torch.zeros((num_classes, K), dtype=torch.float32, device=dets.device)
+        cnt = torch.zeros((num_classes,), dtype=torch.int32, device=dets.device)
+        pos = torch.zeros((K,), dtype=torch.long, device=dets.device)
+        for j in range(num_classes):  # classes == j split (post_process.py:19-27); tiny host loop over <= 80 classes
+            idx = torch.nonzero(cls == j).flatten()
+            m = idx.numel()
+            if m:
+                lists_b[j, :m], lists_s[j, :m], cnt[j] = boxes[idx], scores[idx], m
+                pos[idx] = torch.arange(m, device=dets.device)
+        so, _, _ = soft_nms(lists_b, lists_s, cnt)
+        scores = so[cls.long(), pos]
+        alive = scores > 0
+    else:
+        alive = torch.ones_like(scores, dtype=torch.bool)
+    s_alive = scores[alive]
+    if s_alive.numel() > max_per_image:  # np.partition threshold, ties may exceed max_per_image (post_process.py:54-60)
+        thresh = torch.sort(s_alive)[0][s_alive.numel() - max_per_image]
+        alive = alive & (scores >= thresh)
+    return boxes[alive], scores[alive], cls[alive]

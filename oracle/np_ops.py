@@ -136,16 +136,17 @@ def soft_nms(dets, sigma=0.5, Nt=0.5, threshold=0.001, method=2):
     while i < N:
         maxscore = dets[i, 4]
         maxpos = i
-        tx1, ty1, tx2, ty2, ts = dets[i].copy()
         pos = i + 1
         while pos < N:
             if maxscore < dets[pos, 4]:
                 maxscore = dets[pos, 4]
                 maxpos = pos
             pos += 1
-        dets[i] = dets[maxpos]
-        dets[maxpos] = (tx1, ty1, tx2, ty2, ts)
-        tx1, ty1, tx2, ty2, ts = dets[i].copy()
+        if maxpos != i:  # swap whole rows (extra columns, e.g. an id tag, travel with the box)
+            tmp = dets[i].copy()
+            dets[i] = dets[maxpos]
+            dets[maxpos] = tmp
+        tx1, ty1, tx2, ty2 = dets[i, :4]
         pos = i + 1
         while pos < N:
             x1, y1, x2, y2 = dets[pos, :4]

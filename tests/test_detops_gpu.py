@@ -260,3 +260,62 @@ def test_pp_selected_data_flow():
     np.testing.assert_array_equal(s.cpu().numpy()[:cnt], v[kidx])
     np.testing.assert_array_equal(b.cpu().numpy()[:cnt], boxes[i][kidx])
     assert (l.cpu().numpy()[:cnt] == 0).all()
+
+
+def test_soft_nms_vs_published_algorithm():
+    """md_soft_nms vs the oracle's restatement of the published CenterNet soft_nms (parity unpinned: the Cython
+    module is not in the reference).  Compared as sets keyed by original index: survivors and their decayed scores."""
+    from minddet_amd import det_ops
+
+    rng = np.random.default_rng(2)
+    for n, method in [(100, 2), (37, 2), (100, 1), (1, 2), (300, 2)]:
+        cx, cy = rng.uniform(0, 200, n), rng.uniform(0, 150, n)
+        w, h = rng.uniform(10, 80, n), rng.uniform(10, 80, n)
+        boxes = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).astype(np.float32)
+        scores = (rng.uniform(0.01, 1, n) + np.arange(n) * 1e-6).astype(np.float32)
+        so, order, num = det_ops.soft_nms(T(boxes), T(scores), method=method)
+        so, order, num = so.cpu().numpy(), order.cpu().numpy(), int(num[0])
+        rows = np.concatenate([boxes, scores[:, None]], 1).astype(np.float32)
+        tagged = np.concatenate([rows, np.arange(n, dtype=np.float32)[:, None]], 1)   # 6th column: original index
+        cnt = np_ops.soft_nms(tagged, method=method)
+        surv = {int(r[5]): r[4] for r in tagged[:cnt]}
+        got = {i: so[i] for i in range(n) if so[i] > 0}
+        assert set(got) == set(surv) and num == cnt
+        for i in got:
+            assert abs(got[i] - surv[i]) <= 2e-6 * max(1.0, abs(surv[i])), (i, got[i], surv[i])
+        assert sorted(order[:num].tolist()) == sorted(surv)
+
+
+def test_centernet_post_process_merge():
+    """post_process + merge_outputs (centernet/src/post_process.py:10-61) on device vs numpy."""
+    from minddet_amd import det_ops
+
+    rng = np.random.default_rng(4)
+    K, C = 100, 80
+    cx, cy = rng.uniform(0, 128, K), rng.uniform(0, 128, K)
+    w, h = rng.uniform(4, 40, K), rng.uniform(4, 40, K)
+    dets = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, np.sort(rng.uniform(0.02, 0.9, K))[::-1],
+                     rng.integers(0, 6, K)], 1).astype(np.float32)
+    c, s, out_hw, scale = np.array([320.0, 240.0], np.float32), 640.0, (128, 128), 1.0
+    boxes, scores, cls = det_ops.centernet_post_process(T(dets), c, s, out_hw, scale, C, soft=True)
+    tr = det_ops.get_affine_transform(c, s, (128, 128))
+    # rot = 0: pure scale + shift: feature (64,64) -> image centre
+    np.testing.assert_allclose(tr @ np.array([64.0, 64.0, 1.0]), c, atol=1e-4)
+    ref_boxes = np.concatenate([dets[:, 0:2].astype(np.float64) @ tr[:, :2].T + tr[:, 2],
+                                dets[:, 2:4].astype(np.float64) @ tr[:, :2].T + tr[:, 2]], 1).astype(np.float32) / scale
+    surv_scores = np.zeros(K, np.float32)
+    for j in range(C):
+        idx = np.nonzero(dets[:, 5] == j)[0]
+        if len(idx) == 0:
+            continue
+        tagged = np.concatenate([ref_boxes[idx], dets[idx, 4:5], idx[:, None].astype(np.float32)], 1).astype(np.float32)
+        cnt = np_ops.soft_nms(tagged, method=2)
+        for r in tagged[:cnt]:
+            surv_scores[int(r[5])] = r[4]
+    alive = surv_scores > 0
+    if alive.sum() > 100:
+        sa = surv_scores[alive]
+        alive &= surv_scores >= np.partition(sa, len(sa) - 100)[len(sa) - 100]
+    np.testing.assert_allclose(boxes.cpu().numpy(), ref_boxes[alive], atol=1e-3)
+    np.testing.assert_allclose(scores.cpu().numpy(), surv_scores[alive], rtol=3e-6, atol=1e-7)
+    np.testing.assert_array_equal(cls.cpu().numpy(), dets[alive, 5].astype(np.int32))
