@@ -112,3 +112,14 @@ def test_known_answer_shapes_from_reference_comments():
                                              rng.uniform(0, 1, (1, 2, 28, 42)).astype(np.float32))
     assert det.shape == (1, 100, 6) and (np.diff(det[0, :, 4]) <= 0).all()
     assert ((cls >= 0) & (cls < 80)).all() and (inds < 28 * 42).all()
+
+
+def test_soft_nms_known_answers():
+    # two identical boxes: the second is decayed by exp(-1/0.5) = e^-2; a disjoint box is untouched
+    d = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 9, 0.8], [50, 50, 59, 59, 0.7]], np.float32)
+    n = np_ops.soft_nms(d, method=2)
+    assert n == 3
+    np.testing.assert_allclose(sorted(d[:, 4]), sorted([0.9, 0.8 * np.exp(-2.0), 0.7]), rtol=1e-6)
+    # hard variant removes it (weight 0 -> score 0 < threshold)
+    d = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 9, 0.8], [50, 50, 59, 59, 0.7]], np.float32)
+    assert np_ops.soft_nms(d, method=3) == 2
