@@ -86,6 +86,13 @@ typedef struct md_iou_attrs {
  * (NULL -> eps 0).  pointpillars/src/core/box_np_ops.py:639-679 */
 int md_iou_aligned(MD_AOT_ARGS);
 
+typedef struct md_rotate_iou_attrs {
+    int32_t criterion; /* -1 IoU, 0 inter/area(box), 1 inter/area(query), 2 raw intersection */
+} md_rotate_iou_attrs;
+/* rotate_iou_kernel_eval (pointpillars/eval_gpu/rotate_iou.py:264-340): in boxes[N,5] f32 (cx,cy,dx,dy,angle),
+ * query[K,5] f32 ; out iou[N,K] f32.  The reference kernel runs under numba.cuda and has no fixture: parity unpinned. */
+int md_rotate_iou_eval(MD_AOT_ARGS);
+
 typedef struct md_nms_attrs {
     float iou_threshold;
     float eps;         /* mode 0 only */

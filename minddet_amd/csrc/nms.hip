@@ -393,6 +393,109 @@ __global__ __launch_bounds__(256) void rot_pair_matrix_kernel(const float *__res
     out[idx] = IOU ? so / fmaxf(A[14] + B[14] - so, ROT_EPS) : so;
 }
 
+// rotate_iou_kernel_eval (pointpillars/eval_gpu/rotate_iou.py:167-302): the numba.cuda N x K rotated IoU with the
+// point-in-quadrilateral + segment-intersection + pseudo-angle insertion sort formulation and the `criterion`
+// switch.  One lane per pair; polygon scratch in LDS, slot-major.
+__device__ __forceinline__ void rie_corners(const float *rb, float *c) {
+    const float a_cos = cosf(rb[4]), a_sin = sinf(rb[4]);
+    const float cx[4] = {-rb[2] / 2, -rb[2] / 2, rb[2] / 2, rb[2] / 2};
+    const float cy[4] = {-rb[3] / 2, rb[3] / 2, rb[3] / 2, -rb[3] / 2};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        c[2 * i] = a_cos * cx[i] + a_sin * cy[i] + rb[0];
+        c[2 * i + 1] = -a_sin * cx[i] + a_cos * cy[i] + rb[1];
+    }
+}
+__device__ __forceinline__ bool rie_in_quad(float px, float py, const float *c) {
+    const float ab0 = c[2] - c[0], ab1 = c[3] - c[1], ad0 = c[6] - c[0], ad1 = c[7] - c[1];
+    const float ap0 = px - c[0], ap1 = py - c[1];
+    const float abab = ab0 * ab0 + ab1 * ab1, abap = ab0 * ap0 + ab1 * ap1;
+    const float adad = ad0 * ad0 + ad1 * ad1, adap = ad0 * ap0 + ad1 * ap1;
+    return abab >= abap && abap >= 0 && adad >= adap && adap >= 0;
+}
+__global__ __launch_bounds__(256) void rotate_iou_eval_kernel(const float *__restrict__ boxes, int n,
+                                                               const float *__restrict__ query, int k, int criterion,
+                                                               float *__restrict__ out) {
+    __shared__ float scratch[3 * 24 * 256];
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)n * k) return;
+    const int i0 = (int)(idx / k), j0 = (int)(idx % k);
+    float r1[5], r2[5], c1[8], c2[8];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) { r1[t] = boxes[(size_t)i0 * 5 + t]; r2[t] = query[(size_t)j0 * 5 + t]; }
+    rie_corners(r1, c1);
+    rie_corners(r2, c2);
+    float *px = scratch + threadIdx.x, *py = px + 24 * 256, *vs = py + 24 * 256;
+    int m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (rie_in_quad(c1[2 * i], c1[2 * i + 1], c2)) { px[m * 256] = c1[2 * i]; py[m * 256] = c1[2 * i + 1]; ++m; }
+        if (rie_in_quad(c2[2 * i], c2[2 * i + 1], c1)) { px[m * 256] = c2[2 * i]; py[m * 256] = c2[2 * i + 1]; ++m; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float A0 = c1[2 * i], A1 = c1[2 * i + 1], B0 = c1[2 * ((i + 1) & 3)], B1 = c1[2 * ((i + 1) & 3) + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float C0 = c2[2 * j], C1 = c2[2 * j + 1], D0 = c2[2 * ((j + 1) & 3)], D1 = c2[2 * ((j + 1) & 3) + 1];
+            const float BA0 = B0 - A0, BA1 = B1 - A1, DA0 = D0 - A0, CA0 = C0 - A0, DA1 = D1 - A1, CA1 = C1 - A1;
+            const bool acd = DA1 * CA0 > CA1 * DA0;
+            const bool bcd = (D1 - B1) * (C0 - B0) > (C1 - B1) * (D0 - B0);
+            if (acd != bcd) {
+                const bool abc = CA1 * BA0 > BA1 * CA0, abd = DA1 * BA0 > BA1 * DA0;
+                if (abc != abd && m < 24) {
+                    const float DC0 = D0 - C0, DC1 = D1 - C1;
+                    const float ABBA = A0 * B1 - B0 * A1, CDDC = C0 * D1 - D0 * C1;
+                    const float DH = BA1 * DC0 - BA0 * DC1;
+                    px[m * 256] = (ABBA * DC0 - BA0 * CDDC) / DH;
+                    py[m * 256] = (ABBA * DC1 - BA1 * CDDC) / DH;
+                    ++m;
+                }
+            }
+        }
+    }
+    float ai = 0.f;
+    if (m > 0) {
+        float cx = 0.f, cy = 0.f;
+        for (int i = 0; i < m; ++i) { cx += px[i * 256]; cy += py[i * 256]; }
+        cx /= (float)m;
+        cy /= (float)m;
+        for (int i = 0; i < m; ++i) {
+            float v0 = px[i * 256] - cx, v1 = py[i * 256] - cy;
+            const float d = sqrtf(v0 * v0 + v1 * v1);
+            v0 = v0 / d;
+            v1 = v1 / d;
+            if (v1 < 0) v0 = -2 - v0;
+            vs[i * 256] = v0;
+        }
+        for (int i = 1; i < m; ++i) {
+            if (vs[(i - 1) * 256] > vs[i * 256]) {
+                const float temp = vs[i * 256], tx = px[i * 256], ty = py[i * 256];
+                int j = i;
+                while (j > 0 && vs[(j - 1) * 256] > temp) {
+                    vs[j * 256] = vs[(j - 1) * 256];
+                    px[j * 256] = px[(j - 1) * 256];
+                    py[j * 256] = py[(j - 1) * 256];
+                    --j;
+                }
+                vs[j * 256] = temp; px[j * 256] = tx; py[j * 256] = ty;
+            }
+        }
+        const float ax = px[0], ay = py[0];
+        for (int i = 0; i < m - 2; ++i) {
+            const float bx = px[(i + 1) * 256], by = py[(i + 1) * 256], qx = px[(i + 2) * 256], qy = py[(i + 2) * 256];
+            ai += fabsf(((ax - qx) * (by - qy) - (ay - qy) * (bx - qx)) / 2.0f);
+        }
+    }
+    const float a1 = r1[2] * r1[3], a2 = r2[2] * r2[3];
+    float v;
+    if (criterion == -1) v = ai / (a1 + a2 - ai);
+    else if (criterion == 0) v = ai / a1;
+    else if (criterion == 1) v = ai / a2;
+    else v = ai;
+    out[idx] = v;
+}
+
 __global__ void iou_aligned_kernel(const float *__restrict__ boxes, int n, const float *__restrict__ query, int k,
                                    float eps, float *__restrict__ out) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -532,6 +635,23 @@ extern "C" int md_iou_aligned(MD_AOT_ARGS) {
     const size_t total = (size_t)n * k;
     hipLaunchKernelGGL(iou_aligned_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float *)params[0], (int)n, (const float *)params[1], (int)k, eps, (float *)params[2]);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+
+extern "C" int md_rotate_iou_eval(MD_AOT_ARGS) {
+    // in: boxes[N,5] f32, query[K,5] f32 ; out: iou[N,K] f32.  extra: md_rotate_iou_attrs (NULL -> criterion -1)
+    if (nparam != 3) return MD_ERR_NPARAM;
+    if (!params || !dtype_is(dtypes, 0, "float32") || !dtype_is(dtypes, 1, "float32") || !dtype_is(dtypes, 2, "float32"))
+        return MD_ERR_ARG;
+    const int64_t n = dim(ndims, shapes, 0, 0), k = dim(ndims, shapes, 1, 0);
+    if (n < 0 || k < 0 || dim(ndims, shapes, 0, 1) != 5 || dim(ndims, shapes, 1, 1) != 5) return MD_ERR_ARG;
+    if (n == 0 || k == 0) return MD_OK;
+    if (n > (1 << 24) || k > (1 << 24)) return MD_ERR_SIZE;
+    const int criterion = extra ? ((const md_rotate_iou_attrs *)extra)->criterion : -1;
+    const size_t total = (size_t)n * k;
+    hipLaunchKernelGGL(rotate_iou_eval_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)params[0], (int)n, (const float *)params[1], (int)k, criterion, (float *)params[2]);
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }

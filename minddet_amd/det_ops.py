@@ -643,3 +643,15 @@ def centernet_post_process(dets, c, s, out_hw, scale, num_classes, soft=True, ma
         thresh = torch.sort(s_alive)[0][s_alive.numel() - max_per_image]
         alive = alive & (scores >= thresh)
     return boxes[alive], scores[alive], cls[alive]
+
+
+class _RotIouAttrs(ctypes.Structure):
+    _fields_ = [("criterion", ctypes.c_int32)]
+
+
+def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1):
+    """pointpillars/eval_gpu/rotate_iou.py:305-340: [N,5] x [K,5] (cx,cy,dx,dy,angle) -> [N,K]."""
+    b, q = _f32c(boxes), _f32c(query_boxes)
+    out = torch.empty((b.shape[0], q.shape[0]), dtype=torch.float32, device=b.device)
+    _lib.call("md_rotate_iou_eval", [b, q, out], extra=_RotIouAttrs(int(criterion)))
+    return out

@@ -3,7 +3,7 @@
 Restates the reference's detection-op algorithms on the CPU (plain C in det_oracle.c,
 numpy/torch-CPU in np_ops.py / nets.py).  Only ``tests/``, ``__graft_entry__.smoke()`` and
 the ``cpu_baseline`` leg of ``bench.py`` may import this package; the product package
-``minddet_amd`` never does (tests/test_no_oracle_in_product.py enforces it).
+``minddet_amd`` never does (tests/test_abi_cpu.py::test_product_never_imports_oracle enforces it).
 """
 import ctypes
 import os
@@ -130,6 +130,14 @@ def circle_nms(dets_sorted, thresh):
     mask = np.zeros(max(n, 1), np.uint8)
     lib().orc_circle_nms(_p(d), ctypes.c_int64(n), ctypes.c_float(thresh), _p(mask))
     return mask[:n]
+
+
+def rotate_iou_eval(boxes, query, criterion=-1):
+    """pointpillars/eval_gpu/rotate_iou.py:305-340 semantics: [N,5] x [K,5] -> [N,K]."""
+    b, q = _c(boxes, np.float32), _c(query, np.float32)
+    out = np.zeros((b.shape[0], q.shape[0]), np.float32)
+    lib().orc_rotate_iou_eval(_p(b), ctypes.c_int64(b.shape[0]), _p(q), ctypes.c_int64(q.shape[0]), ctypes.c_int(criterion), _p(out))
+    return out
 
 
 # ---------------------------------------------------------------- reference (oracle/_ref) wrappers

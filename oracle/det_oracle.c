@@ -25,8 +25,8 @@
  * cos/sin/atan2 of the host libm, whose last-bit behaviour is libm-build dependent.
  * The oracle defines them as the double-precision libm function rounded once to float
  * (orc_cosf/orc_sinf/orc_atan2f below).  oracle/_ref (the reference source itself,
- * compiled by oracle/Makefile) is used by tests/test_oracle_vs_ref.py to pin this
- * restatement: identical keep lists, IoU values within 2e-6.
+ * compiled by oracle/Makefile) produced tests/golden/reference_vectors.npz, which
+ * tests/test_oracle_golden.py uses to pin this restatement: identical keep lists, IoU within 2e-6.
  */
 #include <math.h>
 #include <stdint.h>
@@ -298,4 +298,104 @@ int orc_circle_nms(const float *d, int64_t n, float thresh, uint8_t *keepmask) {
         }
     }
     return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------------
+ * rotate_iou_kernel_eval restated: pointpillars/eval_gpu/rotate_iou.py:167-262 (rbbox_to_corners,
+ * point_in_quadrilateral, line_segment_intersection, quadrilateral_intersection, sort_vertex_in_convex_polygon,
+ * area, devRotateIoUEval) and the N x K driver :264-340.  Boxes are 5 floats (cx, cy, dx, dy, angle).
+ * criterion -1: IoU, 0: inter/area1, 1: inter/area2, 2: raw intersection.  The reference runs under numba.cuda
+ * (absent here) and ships no fixture: parity unpinned; cross-checked in tests against orc_rot_overlap.
+ * --------------------------------------------------------------------------------------------------------- */
+static void rie_corners(const float *rb, float *c) {
+    const float a_cos = cosf(rb[4]), a_sin = sinf(rb[4]);
+    const float cx[4] = {-rb[2] / 2, -rb[2] / 2, rb[2] / 2, rb[2] / 2};
+    const float cy[4] = {-rb[3] / 2, rb[3] / 2, rb[3] / 2, -rb[3] / 2};
+    for (int i = 0; i < 4; ++i) {
+        c[2 * i] = a_cos * cx[i] + a_sin * cy[i] + rb[0];
+        c[2 * i + 1] = -a_sin * cx[i] + a_cos * cy[i] + rb[1];
+    }
+}
+static int rie_in_quad(float px, float py, const float *c) {
+    const float ab0 = c[2] - c[0], ab1 = c[3] - c[1], ad0 = c[6] - c[0], ad1 = c[7] - c[1];
+    const float ap0 = px - c[0], ap1 = py - c[1];
+    const float abab = ab0 * ab0 + ab1 * ab1, abap = ab0 * ap0 + ab1 * ap1;
+    const float adad = ad0 * ad0 + ad1 * ad1, adap = ad0 * ap0 + ad1 * ap1;
+    return abab >= abap && abap >= 0 && adad >= adap && adap >= 0;
+}
+static int rie_seg(const float *p1, const float *p2, int i, int j, float *t) {
+    const float A0 = p1[2 * i], A1 = p1[2 * i + 1], B0 = p1[2 * ((i + 1) % 4)], B1 = p1[2 * ((i + 1) % 4) + 1];
+    const float C0 = p2[2 * j], C1 = p2[2 * j + 1], D0 = p2[2 * ((j + 1) % 4)], D1 = p2[2 * ((j + 1) % 4) + 1];
+    const float BA0 = B0 - A0, BA1 = B1 - A1, DA0 = D0 - A0, CA0 = C0 - A0, DA1 = D1 - A1, CA1 = C1 - A1;
+    const int acd = DA1 * CA0 > CA1 * DA0;
+    const int bcd = (D1 - B1) * (C0 - B0) > (C1 - B1) * (D0 - B0);
+    if (acd != bcd) {
+        const int abc = CA1 * BA0 > BA1 * CA0, abd = DA1 * BA0 > BA1 * DA0;
+        if (abc != abd) {
+            const float DC0 = D0 - C0, DC1 = D1 - C1;
+            const float ABBA = A0 * B1 - B0 * A1, CDDC = C0 * D1 - D0 * C1;
+            const float DH = BA1 * DC0 - BA0 * DC1, Dx = ABBA * DC0 - BA0 * CDDC, Dy = ABBA * DC1 - BA1 * CDDC;
+            t[0] = Dx / DH;
+            t[1] = Dy / DH;
+            return 1;
+        }
+    }
+    return 0;
+}
+float orc_rotate_iou_eval_pair(const float *r1, const float *r2, int criterion) {
+    float c1[8], c2[8], pts[48];
+    rie_corners(r1, c1);
+    rie_corners(r2, c2);
+    int n = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (rie_in_quad(c1[2 * i], c1[2 * i + 1], c2)) { pts[2 * n] = c1[2 * i]; pts[2 * n + 1] = c1[2 * i + 1]; ++n; }
+        if (rie_in_quad(c2[2 * i], c2[2 * i + 1], c1)) { pts[2 * n] = c2[2 * i]; pts[2 * n + 1] = c2[2 * i + 1]; ++n; }
+    }
+    float t[2];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (rie_seg(c1, c2, i, j, t) && n < 24) { pts[2 * n] = t[0]; pts[2 * n + 1] = t[1]; ++n; }
+    float ai = 0.f;
+    if (n > 0) {
+        float cx = 0.f, cy = 0.f, vs[24];
+        for (int i = 0; i < n; ++i) { cx += pts[2 * i]; cy += pts[2 * i + 1]; }
+        cx /= (float)n;
+        cy /= (float)n;
+        for (int i = 0; i < n; ++i) {
+            float v0 = pts[2 * i] - cx, v1 = pts[2 * i + 1] - cy;
+            const float d = sqrtf(v0 * v0 + v1 * v1);
+            v0 = v0 / d;
+            v1 = v1 / d;
+            if (v1 < 0) v0 = -2 - v0;
+            vs[i] = v0;
+        }
+        for (int i = 1; i < n; ++i) {
+            if (vs[i - 1] > vs[i]) {
+                const float temp = vs[i], tx = pts[2 * i], ty = pts[2 * i + 1];
+                int j = i;
+                while (j > 0 && vs[j - 1] > temp) {
+                    vs[j] = vs[j - 1];
+                    pts[2 * j] = pts[2 * j - 2];
+                    pts[2 * j + 1] = pts[2 * j - 1];
+                    --j;
+                }
+                vs[j] = temp;
+                pts[2 * j] = tx;
+                pts[2 * j + 1] = ty;
+            }
+        }
+        for (int i = 0; i < n - 2; ++i) {
+            const float *a = pts, *b = pts + 2 * i + 2, *c = pts + 2 * i + 4;
+            ai += fabsf(((a[0] - c[0]) * (b[1] - c[1]) - (a[1] - c[1]) * (b[0] - c[0])) / 2.0f);
+        }
+    }
+    const float a1 = r1[2] * r1[3], a2 = r2[2] * r2[3];
+    if (criterion == -1) return ai / (a1 + a2 - ai);
+    if (criterion == 0) return ai / a1;
+    if (criterion == 1) return ai / a2;
+    return ai;
+}
+void orc_rotate_iou_eval(const float *boxes, int64_t n, const float *query, int64_t k, int criterion, float *out) {
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < k; ++j) out[i * k + j] = orc_rotate_iou_eval_pair(boxes + i * 5, query + j * 5, criterion);
 }
