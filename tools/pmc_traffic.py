@@ -1,7 +1,7 @@
 """Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) into the
 HBM traffic of the dominant kernel, corrected as MI355X_MICROARCH.md (HBM section) prescribes for gfx950:
 FETCH_SIZE (KB) reports half of the bytes of wide coalesced reads -> x2; WRITE_SIZE (KB) is exact for 16-B
-streaming stores.  Usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <steps_profiled> <out.json>"""
+streaming stores.  Usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <steps_profiled> <batch_per_gpu> <out.json>"""
 import collections
 import csv
 import glob
@@ -20,13 +20,15 @@ def per_kernel(d):
 
 fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
 steps = int(sys.argv[3])
-conv = [k for k in fetch if "conv_igemm_kernel" in k]
+batch = int(sys.argv[4])
+conv = [k for k in fetch if "conv_igemm_kernel" in k or "conv3x3_halo_kernel" in k or "conv_ring32_kernel" in k]
 f_kb = sum(fetch[k][0] for k in conv)
 w_kb = sum(write[k][0] for k in conv)
 n = sum(fetch[k][1] for k in conv)
-out = {"kernel": "conv_igemm_kernel (all instantiations)", "profiled_steps": steps, "launches": n,
+out = {"kernel": "conv_igemm_kernel + conv3x3_halo_kernel (all conv/FC launches)", "profiled_steps": steps,
+       "batch_per_gpu": batch, "launches": n,
        "FETCH_SIZE_KB_raw": f_kb, "WRITE_SIZE_KB": w_kb, "fetch_correction": 2.0,
        "hbm_bytes_per_step": (2.0 * f_kb + w_kb) * 1024 / steps,
        "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024 / n}
-json.dump(out, open(sys.argv[4], "w"), indent=1)
+json.dump(out, open(sys.argv[5], "w"), indent=1)
 print(out)
