@@ -92,13 +92,13 @@ def main():
         nn_ops.conv2d = timed_conv2d
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     dt = time.perf_counter() - t0
     nn_ops.conv2d = orig_conv2d
     if world > 1:
@@ -119,7 +119,7 @@ def main():
             tj = json.load(open(tp))
             if tj.get("batch_per_gpu") == B:
                 traffic = round(tj["hbm_bytes_per_launch"] / 1e6, 2)
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (implicit-GEMM conv/FC, all launches)",
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_halo_kernel (every conv/FC launch of the step)",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "MB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_conv_traffic.json)",
                     "algorithmic_mb_per_launch": round(sum(r[6] for r in records) / len(records) / 1e6, 2),
