@@ -129,7 +129,8 @@ int md_circle_nms(MD_AOT_ARGS);
  * ------------------------------------------------------------------------------------------ */
 typedef struct md_conv2d_attrs {
     int32_t kh, kw, stride, pad; /* square stride / symmetric zero padding */
-    int32_t relu;                /* 1: ReLU after bias (+ residual) */
+    int32_t relu;                /* activation: 0 none; 1 ReLU applied after bias (+ residual);
+                                    2 SiLU applied after bias, BEFORE the residual add (x + act(conv(x))) */
     int32_t variant;             /* 0 = auto (default). Tile/staging variant for A/B measurements:
                                     1 register-staged 128x128, 2 LDS-DMA 128x128, 3 LDS-DMA 256x256 */
     /* generalised addressing, used when adv != 0 (all zero = plain conv).  The op then computes, for
@@ -174,6 +175,13 @@ typedef struct md_slice_attrs {
 } md_slice_attrs;
 /* in x[..., C] bf16 ; out y[..., width] f32 = x[..., c0:c0+width].  extra: md_slice_attrs. */
 int md_slice_cast(MD_AOT_ARGS);
+
+/* copy a tensor into a channel slice of a wider one (channel concat of tensors that were not written in place):
+ * in src[N,H,W,C] bf16 ; out dst[N,H,W,Ctot] bf16 (only channels [c0, c0+C) are written).  extra: md_slice_attrs
+ * (c0 = destination offset, width = C) */
+int md_concat_copy(MD_AOT_ARGS);
+/* nearest 2x upsample into a channel slice: in src[N,H,W,C] bf16 ; out dst[N,2H,2W,Ctot] bf16.  extra: md_slice_attrs */
+int md_upsample2x(MD_AOT_ARGS);
 /* in x[N,H,W,C] bf16 ; out y[N,width,H,W] f32 (NCHW, the layout centernet/src/decode.py consumes) */
 int md_nhwc_to_nchw_f32(MD_AOT_ARGS);
 
@@ -319,6 +327,22 @@ int md_gather_rows(MD_AOT_ARGS);
  * (call site pointpillars/src/predict.py:61-78).  in boxes[N,5] (x,y,dx,dy,r) or [N,7] (x,y,z,dx,dy,dz,r) f32 ;
  * out standup[N,4] f32 (xmin,ymin,xmax,ymax) */
 int md_standup_boxes(MD_AOT_ARGS);
+
+/* ------------------------------------------------------------------------------------------
+ * YOLOv5 Detect decode (absent from the reference; Ultralytics v6/v7 convention; parity unpinned)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct md_yolo_attrs {
+    int32_t num_classes, num_anchors;   /* head channels per anchor = 5 + num_classes, anchor-major */
+    float stride;
+    float anchors[6];                   /* (w,h) in pixels for up to 3 anchors of this level */
+    float conf_thres;
+    int32_t out_offset;                 /* first row of this level inside the per-image outputs */
+    int32_t out_total;                  /* rows per image over all levels */
+} md_yolo_attrs;
+/* in head[B,H,W,Cp] bf16 ; out boxes[B,out_total,4] f32 (x1,y1,x2,y2), scores[B,out_total] f32 = obj*max_cls
+ * (-FLT_MAX if obj <= conf_thres or score <= conf_thres), labels[B,out_total] i32 ; only rows
+ * [out_offset, out_offset + H*W*A) are written */
+int md_yolo_decode(MD_AOT_ARGS);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,8 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
     return (uint16_t)(u >> 16);
 }
 
+__device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
+
 constexpr int BK = 64;
 constexpr int ROWB = BK * 2;  // bytes per LDS tile row
 
@@ -497,8 +499,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
             for (int j = 0; j < 2 * FP; ++j) {
                 const int p_local = (wp * FP * 2 + j) * 16 + l16;
                 float v0 = acc4[i][j][0] + bv.x, v1 = acc4[i][j][1] + bv.y, v2 = acc4[i][j][2] + bv.z, v3 = acc4[i][j][3] + bv.w;
-                if (a.relu && !a.res) {
+                if (a.relu == 1 && !a.res) {
                     v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                } else if (a.relu == 2) {
+                    v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
                 }
                 uint2 pk;
                 pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
@@ -518,8 +522,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
                 const int p_local = (wp * FP + j) * 32 + lr;
                 float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
                 float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
-                if (a.relu && !a.res) {
+                if (a.relu == 1 && !a.res) {
                     v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                } else if (a.relu == 2) {
+                    v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
                 }
                 uint2 pk;
                 pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
             for (int k = 0; k < 4; ++k) {
                 float lo = bf2f((uint16_t)(v[k] & 0xffff)) + bf2f((uint16_t)(rv[k] & 0xffff));
                 float hi = bf2f((uint16_t)(v[k] >> 16)) + bf2f((uint16_t)(rv[k] >> 16));
-                if (a.relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                if (a.relu == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
                 v[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
             }
         }
@@ -729,8 +735,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a, int ti
                 const int p_local = (wp * FP + j) * 32 + lr;
                 float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
                 float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
-                if (a.relu && !a.res) {
+                if (a.relu == 1 && !a.res) {
                     v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                } else if (a.relu == 2) {
+                    v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
                 }
                 uint2 pk;
                 pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
@@ -753,7 +761,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a, int ti
             for (int k = 0; k < 4; ++k) {
                 float lo = bf2f((uint16_t)(v[k] & 0xffff)) + bf2f((uint16_t)(rv[k] & 0xffff));
                 float hi = bf2f((uint16_t)(v[k] >> 16)) + bf2f((uint16_t)(rv[k] >> 16));
-                if (a.relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                if (a.relu == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
                 v[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
             }
         }
@@ -913,8 +921,10 @@ __global__ __launch_bounds__(256, 3) void conv_ring32_kernel(ConvArgs a) {
                 const int p_local = (wp * FP + j) * 32 + lr;
                 float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
                 float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
-                if (a.relu && !a.res) {
+                if (a.relu == 1 && !a.res) {
                     v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                } else if (a.relu == 2) {
+                    v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
                 }
                 uint2 pk;
                 pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
@@ -938,7 +948,7 @@ __global__ __launch_bounds__(256, 3) void conv_ring32_kernel(ConvArgs a) {
             for (int k = 0; k < 4; ++k) {
                 float lo = bf2f((uint16_t)(v[k] & 0xffff)) + bf2f((uint16_t)(rv[k] & 0xffff));
                 float hi = bf2f((uint16_t)(v[k] >> 16)) + bf2f((uint16_t)(rv[k] >> 16));
-                if (a.relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                if (a.relu == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
                 v[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
             }
         }
@@ -997,7 +1007,7 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     a.N = (int)shapes[0][0]; a.H = (int)shapes[0][1]; a.W = (int)shapes[0][2]; a.Cin = (int)shapes[0][3];
     a.Hf = (int)shapes[4][1]; a.Wf = (int)shapes[4][2]; a.Ctot = (int)shapes[4][3];
     a.kh = at->kh; a.kw = at->kw; a.stride = at->stride; a.pad = at->pad; a.relu = at->relu;
-    if (a.kh < 1 || a.kw < 1 || a.stride < 1 || a.pad < 0) return MD_ERR_ARG;
+    if (a.kh < 1 || a.kw < 1 || a.stride < 1 || a.pad < 0 || a.relu < 0 || a.relu > 2) return MD_ERR_ARG;
     a.adv = at->adv != 0;
     a.korder = at->korder;
     if (!a.adv) {

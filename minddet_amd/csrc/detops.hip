@@ -634,6 +634,35 @@ __global__ void centerpoint_decode_kernel(const uint16_t *__restrict__ head, CpA
     }
 }
 
+// YOLOv5 Detect decode: per (cell, anchor): sigmoid of the 5+nc outputs; xy = (2s - 0.5 + grid) * stride,
+// wh = (2s)^2 * anchor; score = obj * max_c cls_c (single-label mode), label = argmax.
+struct YoloArgs { int H, W, Cp, nc, A; float stride, aw[3], ah[3], thr; int off, total; };
+__global__ void yolo_decode_kernel(const uint16_t *__restrict__ head, YoloArgs a, int B, float *__restrict__ boxes,
+                                   float *__restrict__ scores, int *__restrict__ labels) {
+    const int per = a.H * a.W * a.A;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * per) return;
+    const int b = e / per, r = e % per;
+    const int an = r % a.A, loc = r / a.A;
+    const int gx = loc % a.W, gy = loc / a.W;
+    const uint16_t *h = head + ((size_t)b * a.H * a.W + loc) * a.Cp + an * (5 + a.nc);
+    auto sg = [](float v) { return 1.0f / (1.0f + expf(-v)); };
+    const float sx = sg(rbf2f(h[0])), sy = sg(rbf2f(h[1])), sw = sg(rbf2f(h[2])), sh = sg(rbf2f(h[3])), obj = sg(rbf2f(h[4]));
+    const float cx = (sx * 2.f - 0.5f + (float)gx) * a.stride, cy = (sy * 2.f - 0.5f + (float)gy) * a.stride;
+    const float w = (sw * 2.f) * (sw * 2.f) * a.aw[an], hh = (sh * 2.f) * (sh * 2.f) * a.ah[an];
+    float best = -1.f;
+    int lab = 0;
+    for (int c = 0; c < a.nc; ++c) {
+        const float v = sg(rbf2f(h[5 + c]));
+        if (v > best) { best = v; lab = c; }
+    }
+    const float conf = obj * best;
+    const size_t o = (size_t)b * a.total + a.off + r;
+    *reinterpret_cast<float4 *>(boxes + o * 4) = make_float4(cx - w / 2, cy - hh / 2, cx + w / 2, cy + hh / 2);
+    scores[o] = (obj > a.thr && conf > a.thr) ? conf : -FLT_MAX;
+    labels[o] = lab;
+}
+
 // rotated BEV box (x, y, dx, dy, r) -> axis-aligned "standup" box of its 4 corners:
 // pointpillars/src/core/box_np_ops.py:316-341 (center_to_corner_box2d, origin 0.5, corners @ [[c,-s],[s,c]])
 // + :172-177 (corner_to_standup_nd); call site pointpillars/src/predict.py:61-78.
@@ -933,6 +962,32 @@ extern "C" int md_centerpoint_decode(MD_AOT_ARGS) {
     hipLaunchKernelGGL(centerpoint_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t *)params[0], a, (int)total, (float *)params[1], (int *)params[2], (float *)params[3],
                        (float *)params[4]);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+
+extern "C" int md_yolo_decode(MD_AOT_ARGS) {
+    if (nparam != 4) return MD_ERR_NPARAM;
+    if (!params || !extra || !ndims || ndims[0] != 4) return MD_ERR_ARG;
+    if (!dtype_is(dtypes, 0, "bfloat16") || !dtype_is(dtypes, 1, "float32") || !dtype_is(dtypes, 2, "float32") ||
+        !dtype_is(dtypes, 3, "int32"))
+        return MD_ERR_ARG;
+    const md_yolo_attrs *at = (const md_yolo_attrs *)extra;
+    YoloArgs a;
+    const int B = (int)shapes[0][0];
+    a.H = (int)shapes[0][1]; a.W = (int)shapes[0][2]; a.Cp = (int)shapes[0][3];
+    a.nc = at->num_classes; a.A = at->num_anchors; a.stride = at->stride; a.thr = at->conf_thres;
+    a.off = at->out_offset; a.total = at->out_total;
+    if (a.A < 1 || a.A > 3 || a.nc < 1 || a.A * (5 + a.nc) > a.Cp) return MD_ERR_ARG;
+    for (int i = 0; i < a.A; ++i) { a.aw[i] = at->anchors[2 * i]; a.ah[i] = at->anchors[2 * i + 1]; }
+    const int64_t per = (int64_t)a.H * a.W * a.A;
+    if (a.off < 0 || a.off + per > a.total) return MD_ERR_ARG;
+    if (numel(ndims, shapes, 1) != (int64_t)B * a.total * 4 || numel(ndims, shapes, 2) != (int64_t)B * a.total ||
+        numel(ndims, shapes, 3) != (int64_t)B * a.total)
+        return MD_ERR_ARG;
+    if (B * per == 0) return MD_OK;
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)((B * per + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)params[0], a, B, (float *)params[1], (float *)params[2], (int *)params[3]);
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }

@@ -122,6 +122,23 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const uint16_t *_
     }
 }
 
+// dst[n,h,w,c0+c] = src[n,h/up,w/up,c]  (up = 1: channel-slice copy; up = 2: nearest upsample into a slice)
+__global__ void slice_write_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int N, int H, int W, int C,
+                                   int Ctot, int c0, int up) {
+    const int cv = C / 8;
+    const size_t total = (size_t)N * H * W * cv;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(e % cv);
+        size_t p = e / cv;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int n = (int)(p / H);
+        const int Hs = H / up, Ws = W / up;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(src + (((size_t)n * Hs + h / up) * Ws + w / up) * C + c8 * 8);
+        *reinterpret_cast<u32x4 *>(dst + (((size_t)n * H + h) * W + w) * Ctot + c0 + c8 * 8) = v;
+    }
+}
+
 static inline unsigned grid_for(size_t total) {
     size_t b = (total + 255) / 256;
     return (unsigned)(b > 8192 ? 8192 : (b == 0 ? 1 : b));
@@ -185,6 +202,26 @@ extern "C" int md_nhwc_to_nchw_f32(MD_AOT_ARGS) {
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }
+
+static int slice_write_impl(MD_AOT_ARGS, int up) {
+    if (nparam != 2) return MD_ERR_NPARAM;
+    if (!params || !extra || !ndims || !shapes || ndims[0] != 4 || ndims[1] != 4) return MD_ERR_ARG;
+    if (!dtype_is(dtypes, 0, "bfloat16") || !dtype_is(dtypes, 1, "bfloat16")) return MD_ERR_ARG;
+    const md_slice_attrs *at = (const md_slice_attrs *)extra;
+    const int N = (int)shapes[0][0], Hs = (int)shapes[0][1], Ws = (int)shapes[0][2], C = (int)shapes[0][3];
+    const int H = (int)shapes[1][1], W = (int)shapes[1][2], Ctot = (int)shapes[1][3];
+    if (shapes[1][0] != N || H != Hs * up || W != Ws * up || C % 8 || Ctot % 8 || at->c0 % 8 || at->c0 < 0 ||
+        at->width != C || at->c0 + C > Ctot)
+        return MD_ERR_ARG;
+    const size_t total = (size_t)N * H * W * (C / 8);
+    if (total == 0) return MD_OK;
+    hipLaunchKernelGGL(slice_write_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)params[0], (uint16_t *)params[1], N, H, W, C, Ctot, at->c0, up);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+extern "C" int md_concat_copy(MD_AOT_ARGS) { return slice_write_impl(nparam, params, ndims, shapes, dtypes, stream, extra, 1); }
+extern "C" int md_upsample2x(MD_AOT_ARGS) { return slice_write_impl(nparam, params, ndims, shapes, dtypes, stream, extra, 2); }
 
 extern "C" int md_slice_cast(MD_AOT_ARGS) {
     if (nparam != 2) return MD_ERR_NPARAM;

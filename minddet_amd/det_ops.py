@@ -655,3 +655,18 @@ def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1):
     out = torch.empty((b.shape[0], q.shape[0]), dtype=torch.float32, device=b.device)
     _lib.call("md_rotate_iou_eval", [b, q, out], extra=_RotIouAttrs(int(criterion)))
     return out
+
+
+# ----------------------------------------------------------------------------- YOLOv5 Detect decode
+class _YoloAttrs(ctypes.Structure):
+    _fields_ = [("num_classes", ctypes.c_int32), ("num_anchors", ctypes.c_int32), ("stride", ctypes.c_float),
+                ("anchors", ctypes.c_float * 6), ("conf_thres", ctypes.c_float), ("out_offset", ctypes.c_int32),
+                ("out_total", ctypes.c_int32)]
+
+
+def yolo_decode(head, boxes, scores, labels, num_classes, num_anchors, stride, anchors, conf_thres, out_offset, out_total):
+    at = _YoloAttrs(int(num_classes), int(num_anchors), float(stride))
+    for i, v in enumerate(anchors):
+        at.anchors[i] = float(v)
+    at.conf_thres, at.out_offset, at.out_total = float(conf_thres), int(out_offset), int(out_total)
+    _lib.call("md_yolo_decode", [head, boxes, scores, labels], extra=at)

@@ -40,7 +40,10 @@ class ConvModule:
     """Conv2d [+ BatchNorm2d(eval)] [+ ReLU] -> one md_conv2d call."""
 
     def __init__(self, init, cin, cout, k, stride=1, pad=0, bn=True, relu=True, bias=False, bn_eps=1e-5, std=None,
-                 bias_value=None):
+                 bias_value=None, act=None):
+        # act: None -> `relu` decides ('relu' after the residual add / none); 'silu' -> SiLU before the residual add
+        self.act = act if act is not None else ("relu" if relu else None)
+        relu = self.act == "relu"
         self.cin, self.cout, self.k, self.stride, self.pad, self.relu = cin, cout, k, stride, pad, relu
         self.weight = init.conv(cout, cin, k, std)
         self.bn = init.bn(cout, bn_eps) if bn else None
@@ -49,11 +52,11 @@ class ConvModule:
 
     def to(self, device):
         self.packed = nn_ops.pack_conv(self.weight, bias=self.bias, bn=self.bn, stride=self.stride, pad=self.pad,
-                                       relu=self.relu).to(device)
+                                       relu=self.act).to(device)
         return self
 
-    def __call__(self, x, residual=None):
-        return nn_ops.conv2d(x, self.packed, residual=residual)
+    def __call__(self, x, residual=None, out=None, c_off=0):
+        return nn_ops.conv2d(x, self.packed, residual=residual, out=out, c_off=c_off)
 
     def macs(self, ho, wo):
         return ho * wo * self.cout * self.cin * self.k * self.k
@@ -531,3 +534,162 @@ class RPN:
                     nn_ops.conv2d(x, d.packed, out=out, c_off=c_off)
                 c_off += d.cout
         return out
+
+
+# ----------------------------------------------------------------------------- YOLOv5 (build-authored; parity unpinned)
+def _yconv(init, cin, cout, k=1, s=1, p=None):
+    return ConvModule(init, cin, cout, k, s, k // 2 if p is None else p, bn=True, bn_eps=1e-3, act="silu")
+
+
+class C3:
+    """CSP bottleneck with 3 convs: cv3(concat(m(cv1(x)), cv2(x))), m = n x [x (+) cv2_3x3(cv1_1x1(x))]."""
+
+    def __init__(self, init, c1, c2, n=1, shortcut=True):
+        c_ = c2 // 2
+        self.cv1, self.cv2, self.cv3 = _yconv(init, c1, c_), _yconv(init, c1, c_), _yconv(init, 2 * c_, c2)
+        self.m = [(_yconv(init, c_, c_, 1), _yconv(init, c_, c_, 3)) for _ in range(n)]
+        self.shortcut, self.c_ = shortcut, c_
+
+    def modules(self):
+        return [self.cv1, self.cv2, self.cv3] + [m for pair in self.m for m in pair]
+
+    def __call__(self, x):
+        n, h, w, _ = x.shape
+        cat = torch.empty((n, h, w, 2 * self.c_), dtype=torch.bfloat16, device=x.device)
+        y = self.cv1(x)
+        for i, (a, b) in enumerate(self.m):
+            last = i == len(self.m) - 1
+            if self.shortcut:
+                y = b(a(y), residual=y)          # SiLU first, then the shortcut add (md_conv2d relu code 2)
+                if last:
+                    nn_ops.concat_copy(y, cat, 0)
+            elif last:
+                b(a(y), out=cat, c_off=0)        # no residual: the last 3x3 writes its concat slice in place
+            else:
+                y = b(a(y))
+        self.cv2(x, out=cat, c_off=self.c_)
+        return self.cv3(cat)
+
+
+class SPPF:
+    def __init__(self, init, c1, c2, k=5):
+        c_ = c1 // 2
+        self.cv1, self.cv2, self.k, self.c_ = _yconv(init, c1, c_), _yconv(init, 4 * c_, c2), k, c_
+
+    def modules(self):
+        return [self.cv1, self.cv2]
+
+    def __call__(self, x):
+        n, h, w, _ = x.shape
+        cat = torch.empty((n, h, w, 4 * self.c_), dtype=torch.bfloat16, device=x.device)
+        y = self.cv1(x)
+        nn_ops.concat_copy(y, cat, 0)
+        for i in range(1, 4):
+            y = nn_ops.maxpool2d(y, self.k, 1, self.k // 2, zero_pad=False)
+            nn_ops.concat_copy(y, cat, i * self.c_)
+        return self.cv2(cat)
+
+
+@DETECTORS.register_module
+class YOLOv5:
+    """YOLOv5 (Ultralytics v6/v7 layout): CSPDarknet backbone + PANet head + Detect, single-label decode and
+    class-aware NMS (conf 0.25 / IoU 0.45 / max_det 300 by default).  depth_multiple/width_multiple 0.33/0.5 = yolov5s."""
+    ANCHORS = ((10, 13, 16, 30, 33, 23), (30, 61, 62, 45, 59, 119), (116, 90, 156, 198, 373, 326))
+
+    def __init__(self, depth_multiple=0.33, width_multiple=0.5, num_classes=80, conf_thres=0.25, iou_thres=0.45,
+                 max_det=300, nms_pre=4096, seed=7, train_cfg=None, test_cfg=None):
+        init = ParamInit(seed)
+        ch = lambda c: max(8, int(math.ceil(c * width_multiple / 8) * 8))
+        d = lambda n: max(1, round(n * depth_multiple))
+        c64, c128, c256, c512, c1024 = ch(64), ch(128), ch(256), ch(512), ch(1024)
+        self.b0 = _yconv(init, 3, c64, 6, 2, 2)
+        self.b1 = _yconv(init, c64, c128, 3, 2)
+        self.b2 = C3(init, c128, c128, d(3))
+        self.b3 = _yconv(init, c128, c256, 3, 2)
+        self.b4 = C3(init, c256, c256, d(6))
+        self.b5 = _yconv(init, c256, c512, 3, 2)
+        self.b6 = C3(init, c512, c512, d(9))
+        self.b7 = _yconv(init, c512, c1024, 3, 2)
+        self.b8 = C3(init, c1024, c1024, d(3))
+        self.b9 = SPPF(init, c1024, c1024)
+        self.h10 = _yconv(init, c1024, c512, 1)
+        self.h13 = C3(init, 2 * c512, c512, d(3), False)
+        self.h14 = _yconv(init, c512, c256, 1)
+        self.h17 = C3(init, 2 * c256, c256, d(3), False)
+        self.h18 = _yconv(init, c256, c256, 3, 2)
+        self.h20 = C3(init, 2 * c256, c512, d(3), False)
+        self.h21 = _yconv(init, c512, c512, 3, 2)
+        self.h23 = C3(init, 2 * c512, c1024, d(3), False)
+        self.nc, self.na = num_classes, 3
+        no = self.na * (5 + num_classes)
+        self.detect = [ConvModule(init, c, no, 1, bn=False, relu=False, bias=True, std=0.02) for c in (c256, c512, c1024)]
+        self.strides = (8, 16, 32)
+        self.conf_thres, self.iou_thres, self.max_det, self.nms_pre = conf_thres, iou_thres, max_det, nms_pre
+        self.c = (c256, c512)
+        self._seg = {}
+
+    def conv_modules(self):
+        out = [self.b0, self.b1, self.b3, self.b5, self.b7, self.h10, self.h14, self.h18, self.h21] + self.detect
+        for blk in (self.b2, self.b4, self.b6, self.b8, self.b9, self.h13, self.h17, self.h20, self.h23):
+            out += blk.modules()
+        return out
+
+    def to(self, device):
+        for m in self.conv_modules():
+            m.to(device)
+        return self
+
+    def features(self, x):
+        x = self.b2(self.b1(self.b0(x)))
+        p3 = self.b4(self.b3(x))
+        p4 = self.b6(self.b5(p3))
+        x = self.b9(self.b8(self.b7(p4)))
+        h10 = self.h10(x)
+        n, h, w, c = p4.shape
+        cat = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=x.device)
+        nn_ops.upsample2x(h10, cat, 0)
+        nn_ops.concat_copy(p4, cat, c)
+        h14 = self.h14(self.h13(cat))
+        n, h, w, c = p3.shape
+        cat = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=x.device)
+        nn_ops.upsample2x(h14, cat, 0)
+        nn_ops.concat_copy(p3, cat, c)
+        o3 = self.h17(cat)
+        n, h, w, c = h14.shape
+        cat = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=x.device)
+        self.h18(o3, out=cat, c_off=0)
+        nn_ops.concat_copy(h14, cat, c)
+        o4 = self.h20(cat)
+        n, h, w, c = h10.shape
+        cat = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=x.device)
+        self.h21(o4, out=cat, c_off=0)
+        nn_ops.concat_copy(h10, cat, c)
+        o5 = self.h23(cat)
+        return [d(o) for d, o in zip(self.detect, (o3, o4, o5))]
+
+    def forward(self, images, return_aux=False):
+        heads = self.features(images)
+        B = images.shape[0]
+        dev = images.device
+        total = sum(h.shape[1] * h.shape[2] * self.na for h in heads)
+        boxes = torch.empty((B, total, 4), dtype=torch.float32, device=dev)
+        scores = torch.empty((B, total), dtype=torch.float32, device=dev)
+        labels = torch.empty((B, total), dtype=torch.int32, device=dev)
+        off = 0
+        for h, s, anc in zip(heads, self.strides, self.ANCHORS):
+            det_ops.yolo_decode(h, boxes, scores, labels, self.nc, self.na, s, anc, self.conf_thres, off, total)
+            off += h.shape[1] * h.shape[2] * self.na
+        if (B, total) not in self._seg:
+            self._seg[(B, total)] = torch.arange(0, (B + 1) * total, total, dtype=torch.int32, device=dev)
+        sv, si, sc = det_ops.topk_segmented(scores, self._seg[(B, total)], self.nms_pre, max_segment=total)
+        sb = det_ops.gather_rows(boxes, si, sc)
+        sl = torch.gather(labels, 1, si.long())
+        keep, kidx, num = det_ops.nms_aligned(sb, self.iou_thres, mode=det_ops.NMS_MODE_STRICT, count=sc, group=sl,
+                                              max_output=self.max_det)
+        dets, count = det_ops.pack_detections(sb, sv, sl, kidx, num, self.max_det)
+        if return_aux:
+            return dets, count, dict(heads=heads, boxes=boxes, scores=scores, labels=labels, sel_idx=si, sel_cnt=sc,
+                                     sel_boxes=sb, sel_labels=sl, keep=keep)
+        return dets, count
+
+    __call__ = forward

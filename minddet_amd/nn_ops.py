@@ -81,7 +81,8 @@ def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, relu=False, cin_pad_t
     wk[:, :k_real] = wp.reshape(cout_p, k_real)
     bp = torch.zeros((cout_p,), dtype=torch.float32, device=weight.device)
     bp[:cout] = b.to(weight.device)
-    pc = PackedConv(wk.to(torch.bfloat16).contiguous(), bp.contiguous(), cin_p, cout_o, kh, kw, stride, pad, relu)
+    act = {None: 0, False: 0, True: 1, "relu": 1, "silu": 2, 0: 0, 1: 1, 2: 2}[relu]  # md_conv2d_attrs.relu codes
+    pc = PackedConv(wk.to(torch.bfloat16).contiguous(), bp.contiguous(), cin_p, cout_o, kh, kw, stride, pad, act)
     pc.cin_real = cin
     pc.korder = korder
     return pc
@@ -210,3 +211,18 @@ def nhwc_to_nchw_f32(x, c0, width):
     y = torch.empty((n, width, h, w), dtype=torch.float32, device=x.device)
     _lib.call("md_nhwc_to_nchw_f32", [x, y], extra=_SliceAttrs(c0, width))
     return y
+
+
+def concat_copy(src, dst, c0):
+    """dst[..., c0:c0+C] = src (channel concat of a tensor that could not be produced in place)."""
+    _lib.call("md_concat_copy", [src, dst], extra=_SliceAttrs(int(c0), src.shape[3]))
+    return dst
+
+
+def upsample2x(src, dst=None, c0=0):
+    """Nearest 2x upsample, optionally straight into channels [c0, c0+C) of a wider `dst`."""
+    n, h, w, c = src.shape
+    if dst is None:
+        dst = torch.empty((n, 2 * h, 2 * w, c), dtype=torch.bfloat16, device=src.device)
+    _lib.call("md_upsample2x", [src, dst], extra=_SliceAttrs(int(c0), c))
+    return dst

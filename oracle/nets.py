@@ -41,6 +41,8 @@ def conv_module(m, x, residual=None, quant=False):
     """x NCHW fp32. Mirrors md_conv2d's epilogue order: bias -> (bf16 round) -> +residual -> ReLU -> round."""
     w, b = fold(m)
     y = F.conv2d(x, _q(w, quant), b, stride=m.stride, padding=m.pad)
+    if getattr(m, "act", None) == "silu":  # SiLU first, then the shortcut add (md_conv2d relu code 2)
+        y = y * torch.sigmoid(y)
     if residual is not None:
         y = _q(y, quant) + residual
     if m.relu:
@@ -251,3 +253,53 @@ def rpn_neck_forward(neck, x, quant=False):
             d = neck.deblocks[i - neck.up_start]
             ups.append(deconv_module(d, x, quant) if hasattr(d, "weight_t") else conv_module(d, x, quant=quant))
     return torch.cat(ups, 1)
+
+
+# ----------------------------------------------------------------------------- YOLOv5 oracle (parity unpinned)
+def _c3(blk, x, quant):
+    y = conv_module(blk.cv1, x, quant=quant)
+    for a, b in blk.m:
+        t = conv_module(a, y, quant=quant)
+        y = conv_module(b, t, residual=y if blk.shortcut else None, quant=quant)
+    return conv_module(blk.cv3, torch.cat([y, conv_module(blk.cv2, x, quant=quant)], 1), quant=quant)
+
+
+def _sppf(blk, x, quant):
+    y = conv_module(blk.cv1, x, quant=quant)
+    ys = [y]
+    for _ in range(3):
+        ys.append(F.max_pool2d(ys[-1], blk.k, 1, blk.k // 2))
+    return conv_module(blk.cv2, torch.cat(ys, 1), quant=quant)
+
+
+def yolov5_heads(m, x, quant=False):
+    cm = lambda mod, t: conv_module(mod, t, quant=quant)
+    x = _c3(m.b2, cm(m.b1, cm(m.b0, x)), quant)
+    p3 = _c3(m.b4, cm(m.b3, x), quant)
+    p4 = _c3(m.b6, cm(m.b5, p3), quant)
+    x = _sppf(m.b9, _c3(m.b8, cm(m.b7, p4), quant), quant)
+    h10 = cm(m.h10, x)
+    h14 = cm(m.h14, _c3(m.h13, torch.cat([F.interpolate(h10, scale_factor=2, mode="nearest"), p4], 1), quant))
+    o3 = _c3(m.h17, torch.cat([F.interpolate(h14, scale_factor=2, mode="nearest"), p3], 1), quant)
+    o4 = _c3(m.h20, torch.cat([cm(m.h18, o3), h14], 1), quant)
+    o5 = _c3(m.h23, torch.cat([cm(m.h21, o4), h10], 1), quant)
+    return [cm(d, o) for d, o in zip(m.detect, (o3, o4, o5))]
+
+
+def yolo_decode_np(head_nhwc, nc, na, stride, anchors, conf_thres):
+    """head [B,H,W,C>=na*(5+nc)] float32 -> boxes [B,HWA,4], scores [B,HWA] (-inf where rejected), labels."""
+    B, H, W, _ = head_nhwc.shape
+    h = head_nhwc[..., :na * (5 + nc)].reshape(B, H, W, na, 5 + nc).astype(np.float32)
+    s = (1.0 / (1.0 + np.exp(-h.astype(np.float64)))).astype(np.float32)
+    gy, gx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    cx = (s[..., 0] * 2 - 0.5 + gx[None, :, :, None]) * np.float32(stride)
+    cy = (s[..., 1] * 2 - 0.5 + gy[None, :, :, None]) * np.float32(stride)
+    an = np.asarray(anchors, np.float32).reshape(na, 2)
+    w = (s[..., 2] * 2) ** 2 * an[None, None, None, :, 0]
+    hh = (s[..., 3] * 2) ** 2 * an[None, None, None, :, 1]
+    obj, cls = s[..., 4], s[..., 5:]
+    best, lab = cls.max(-1), cls.argmax(-1)
+    conf = obj * best
+    ok = (obj > np.float32(conf_thres)) & (conf > np.float32(conf_thres))
+    boxes = np.stack([cx - w / 2, cy - hh / 2, cx + w / 2, cy + hh / 2], -1).reshape(B, -1, 4).astype(np.float32)
+    return boxes, np.where(ok, conf, -np.inf).reshape(B, -1).astype(np.float32), lab.reshape(B, -1).astype(np.int32)
