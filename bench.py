@@ -49,8 +49,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("MD_FORCE_DIST") == "1"  # MD_FORCE_DIST: exercise the RCCL path with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -69,20 +73,20 @@ def main():
     records = []
     orig_conv2d = nn_ops.conv2d
 
-    def timed_conv2d(x, pc, residual=None, relu=None, out=None):
+    def timed_conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        y = orig_conv2d(x, pc, residual=residual, relu=relu, out=out)
+        y = orig_conv2d(x, pc, residual=residual, relu=relu, out=out, variant=variant, c_off=c_off)
         e1.record()
         n, ho, wo, _ = y.shape
-        byts = 2.0 * (x.numel() + y.numel() + pc.cout * pc.cin_real * pc.kh * pc.kw + (residual.numel() if residual is not None else 0))
+        byts = 2.0 * (x.numel() + n * ho * wo * pc.cout + pc.cout * pc.cin_real * pc.kh * pc.kw + (residual.numel() if residual is not None else 0))
         records.append((e0, e1, 2.0 * n * ho * wo * pc.cout * pc.cin_real * pc.kh * pc.kw, tuple(x.shape), pc.cout, pc.kh, byts))
         return y
 
     def step():
         dets, count = model.forward(images)
-        if world > 1:
-            return gather_detections(dets, count)
+        if use_dist:
+            return gather_detections(dets, count, force=True)
         return dets, count
 
     for _ in range(args.warmup):
@@ -91,17 +95,17 @@ def main():
     if instrument:
         nn_ops.conv2d = timed_conv2d
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier(device_ids=[local_rank])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier(device_ids=[local_rank])
     dt = time.perf_counter() - t0
     nn_ops.conv2d = orig_conv2d
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -117,7 +121,7 @@ def main():
         tp = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
         if os.path.exists(tp):  # PMC passes are separate rocprofv3 runs (tools/pmc_traffic.py); same config only
             tj = json.load(open(tp))
-            if tj.get("batch_per_gpu") == B:
+            if tj.get("batch_per_gpu") == B and type(model).__name__ == "FasterRCNN":
                 traffic = round(tj["hbm_bytes_per_launch"] / 1e6, 2)
         roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_halo_kernel (every conv/FC launch of the step)",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
@@ -141,8 +145,9 @@ def main():
         with open(args.dump_convs, "w") as f:
             json.dump(rows, f, indent=1)
 
+    is_frcnn = type(model).__name__ == "FasterRCNN"
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and is_frcnn:
         from oracle import nets
 
         try:
@@ -165,19 +170,24 @@ def main():
 
     if rank == 0:
         total_images = world * B * args.steps
+        wl = ("faster_rcnn_r50_fpn_800x1344 (BASELINE.json configs[2])" if is_frcnn
+              else f"{os.path.basename(args.config)} {H}x{W} (secondary workload)")
+        gmac = (model.macs_per_image(H, W) / 1e9 if is_frcnn else
+                (sum(r[2] for r in records) / 2 / max(args.steps, 1) / B / 1e9 if records else None))
         line = {
-            "metric": "images/sec, Faster R-CNN R50-FPN inference, COCO-shaped 1333x800 (padded 800x1344)",
+            "metric": ("images/sec, Faster R-CNN R50-FPN inference, COCO-shaped 1333x800 (padded 800x1344)" if is_frcnn
+                       else f"images/sec, {type(model).__name__} inference {H}x{W}"),
             "value": round(total_images / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "faster_rcnn_r50_fpn_800x1344 (BASELINE.json configs[2])", "batch_per_gpu": B,
+            "config": {"workload": wl, "batch_per_gpu": B,
                        "global_batch": world * B, "parallelism": f"dp{world} (image sharding + all_gather of detections)",
-                       "gmac_per_image": round(model.macs_per_image(H, W) / 1e9, 1), "weights": "random init, seed 7"},
+                       "gmac_per_image": None if gmac is None else round(gmac, 2), "weights": "random init, seed 7"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "lib": os.path.relpath(_lib.LIB_PATH, ROOT),
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

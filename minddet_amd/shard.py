@@ -37,9 +37,10 @@ def unpack_gathered(buf):
     return buf[:, :M, :6].contiguous(), buf[:, M, 0].to(torch.int32)
 
 
-def gather_detections(dets, count, group=None):
-    """All ranks end up with the detections of the whole global batch, in input order."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def gather_detections(dets, count, group=None, force=False):
+    """All ranks end up with the detections of the whole global batch, in input order.
+    `force` runs the collective even for a single rank (used to exercise the RCCL path on one GPU)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return dets, count
     world = dist.get_world_size(group)
     buf = pack_for_gather(dets, count)
