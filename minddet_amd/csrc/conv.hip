@@ -992,7 +992,7 @@ extern "C" int md_conv2d_cout_tile(int cout) { return cout > 64 ? 128 : (cout > 
 
 extern "C" int md_conv2d(MD_AOT_ARGS) {
     if (nparam != 5) return MD_ERR_NPARAM;
-    if (!params || !extra || !params[0] || !params[1] || !params[2] || !params[4]) return MD_ERR_ARG;
+    if (!params || !extra || !params[1] || !params[2]) return MD_ERR_ARG;  // x / y may be null for an empty batch
     if (!dtype_is(dtypes, 0, "bfloat16") || !dtype_is(dtypes, 1, "bfloat16") || !dtype_is(dtypes, 2, "float32") ||
         !dtype_is(dtypes, 4, "bfloat16"))
         return MD_ERR_ARG;
@@ -1034,6 +1034,7 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     if (params[3] && (ndims[3] != 4 || numel(ndims, shapes, 3) != numel(ndims, shapes, 4))) return MD_ERR_ARG;
     const long long M = (long long)a.N * a.Ho * a.Wo;
     if (M <= 0) return MD_OK;
+    if (!params[0] || !params[4]) return MD_ERR_ARG;
     if (M > 0x7fffffffLL || (long long)a.N * a.H * a.W > 0x7fffffffLL / 2 || a.H > 32000 || a.W > 32000)
         return MD_ERR_SIZE;
     a.M = (int)M;

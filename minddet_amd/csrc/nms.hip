@@ -658,7 +658,7 @@ extern "C" int md_rotate_iou_eval(MD_AOT_ARGS) {
 
 extern "C" int md_nms_aligned(MD_AOT_ARGS) {
     if (nparam != 6 && nparam != 7) return MD_ERR_NPARAM;
-    if (!params || !extra || !params[0]) return MD_ERR_ARG;
+    if (!params || !extra) return MD_ERR_ARG;  // params[0] may be a null pointer for an empty tensor
     if (!dtype_is(dtypes, 0, "float32") || !dtype_is(dtypes, 1, "int32") || !dtype_is(dtypes, 2, "int32") ||
         !dtype_is(dtypes, 3, "uint8") || !dtype_is(dtypes, 4, "int32") || !dtype_is(dtypes, 5, "int32"))
         return MD_ERR_ARG;
@@ -672,6 +672,7 @@ extern "C" int md_nms_aligned(MD_AOT_ARGS) {
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) return MD_OK;
     if (n == 0) return hipMemsetAsync(params[5], 0, sizeof(int) * B, s) == hipSuccess ? MD_OK : MD_ERR_HIP;
+    if (!params[0]) return MD_ERR_ARG;
     const int cb = (int)((n + TILE - 1) / TILE);
     Scratch ws;
     int rc = ws.acquire((size_t)B * n * cb * 8, nparam, params, ndims, shapes, 6, s);

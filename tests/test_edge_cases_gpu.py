@@ -1,0 +1,88 @@
+"""-m gpu: edge cases through the C ABI -- empty inputs, ragged / degenerate data, size limits, wrong dtypes.
+Errors surface as return codes (iou-bev-nms-org.cpp:238 convention), mapped to MindDetHipError by the host."""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs MI355X")]
+DEV = "cuda:0"
+
+
+def test_empty_inputs_are_ok():
+    from minddet_amd import det_ops, nn_ops
+
+    z7 = torch.zeros((0, 7), device=DEV)
+    assert det_ops.boxes_iou_bev(z7, torch.zeros((5, 7), device=DEV)).shape == (0, 5)
+    assert det_ops.boxes_iou_bev(torch.zeros((5, 7), device=DEV), z7).shape == (5, 0)
+    assert det_ops.iou_jit(torch.zeros((0, 4), device=DEV), torch.zeros((3, 4), device=DEV)).shape == (0, 3)
+    keep, num = det_ops.NumGpu()(z7, 0.5)
+    assert int(num[0]) == 0
+    m, i, n = det_ops.nms_aligned(torch.zeros((0, 4), device=DEV), 0.5, mode=2)
+    assert int(n[0]) == 0
+    v, i, c = det_ops.topk_segmented(torch.zeros((0,), device=DEV), torch.zeros((3,), dtype=torch.int32, device=DEV), 10)
+    assert c.tolist() == [0, 0] and (i == 0).all()
+    pc = nn_ops.pack_conv(torch.randn((64, 64, 3, 3)), stride=1, pad=1).to(DEV)
+    y = nn_ops.conv2d(torch.zeros((0, 8, 8, 64), dtype=torch.bfloat16, device=DEV), pc)
+    assert y.shape == (0, 8, 8, 64)
+    out = det_ops.roi_align([torch.zeros((1, 8, 8, 16), dtype=torch.bfloat16, device=DEV)], torch.zeros((0, 5), device=DEV), 7, [0.25])
+    assert out.shape == (0, 7, 7, 16)
+
+
+def test_degenerate_boxes_do_not_crash():
+    from minddet_amd import det_ops
+
+    b = torch.zeros((130, 7), device=DEV)
+    b[:, 3:5] = 1.0
+    b[3, 0] = float("nan")
+    b[7, 3] = float("inf")
+    b[9, 6] = 1e30
+    keep, num = det_ops.NumGpu()(b, 0.5)
+    torch.cuda.synchronize()
+    assert 1 <= int(num[0]) <= 130
+    a = torch.tensor([[0.0, 0.0, -5.0, 3.0]], device=DEV)  # inverted box: zero IoU by the iw > 0 test
+    assert float(det_ops.iou_jit(a, a)[0, 0]) == 0.0
+
+
+def test_size_limits_and_bad_arguments_return_codes():
+    from minddet_amd import _lib, det_ops, nn_ops
+
+    with pytest.raises(_lib.MindDetHipError, match="rc=4"):
+        det_ops.nms_aligned(torch.zeros((70000, 4), device=DEV), 0.5, mode=2)
+    with pytest.raises(_lib.MindDetHipError, match="rc=4"):
+        det_ops.topk_segmented(torch.zeros((100,), device=DEV), torch.tensor([0, 100], dtype=torch.int32, device=DEV), 5000)
+    with pytest.raises(_lib.MindDetHipError, match="rc=2"):
+        _lib.call("NmsGpu", [torch.zeros((4, 6), device=DEV), torch.zeros((1,), device=DEV),
+                             torch.zeros((4,), dtype=torch.int64, device=DEV), torch.zeros((1,), dtype=torch.int32, device=DEV)])
+    with pytest.raises(_lib.MindDetHipError, match="rc=2"):
+        _lib.call("NmsGpu", [torch.zeros((4, 7), device=DEV), torch.zeros((1,), device=DEV),
+                             torch.zeros((4,), dtype=torch.int32, device=DEV), torch.zeros((1,), dtype=torch.int32, device=DEV)])
+    with pytest.raises(_lib.MindDetHipError, match="rc=1"):
+        _lib.call("md_iou_aligned", [torch.zeros((4, 4), device=DEV)])
+    pc = nn_ops.pack_conv(torch.randn((64, 64, 3, 3)), stride=1, pad=1).to(DEV)
+    with pytest.raises(_lib.MindDetHipError, match="rc=2"):  # output shape does not match the conv geometry
+        nn_ops.conv2d(torch.zeros((1, 8, 8, 64), dtype=torch.bfloat16, device=DEV), pc,
+                      out=torch.zeros((1, 9, 8, 64), dtype=torch.bfloat16, device=DEV))
+    with pytest.raises(_lib.MindDetHipError):
+        _lib.call("NmsGpu", [torch.zeros((4, 7)), torch.zeros((1,)), torch.zeros((4,), dtype=torch.int64),
+                             torch.zeros((1,), dtype=torch.int32)])  # host tensors are refused before the call
+
+
+def test_caller_workspace_is_used():
+    from minddet_amd import _lib, det_ops
+    import oracle
+
+    rng = np.random.default_rng(1)
+    b = np.zeros((500, 7), np.float32)
+    b[:, :2] = rng.uniform(-10, 10, (500, 2)); b[:, 3:6] = rng.uniform(1, 4, (500, 3)); b[:, 6] = rng.uniform(-3, 3, 500)
+    bt = torch.from_numpy(b).to(DEV)
+    keep = torch.empty((500,), dtype=torch.int32, device=DEV)
+    num = torch.empty((1,), dtype=torch.int32, device=DEV)
+    need = (500 * 80 + 255) // 256 * 256 + 500 * 8 * 8
+    ws = torch.empty((need,), dtype=torch.uint8, device=DEV)
+    _lib.call("boxes_iou_nms_gpu", [bt, torch.tensor([0.3], device=DEV), keep, num, ws])
+    k_o, n_o = oracle.nms_rot_aot(b, 0.3)
+    assert int(num[0]) == n_o and (keep.cpu().numpy() == k_o).all()
+    with pytest.raises(_lib.MindDetHipError, match="rc=4"):  # workspace too small
+        _lib.call("boxes_iou_nms_gpu", [bt, torch.tensor([0.3], device=DEV), keep, num, ws[:1000]])
