@@ -483,7 +483,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
             const int p_local = e / CPP, cc = e % CPP;
             const int m = pix0 + p_local, c = cout0 + cc * 8;
             rres[it] = (u32x4){0u, 0u, 0u, 0u};
-            if (m < a.M && c < a.Cout) rres[it] = *reinterpret_cast<const u32x4 *>(a.res + out_offset(m, c));
+            if (m < a.M && c < a.Cout) rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + out_offset(m, c)));
         }
     }
     // bias (+ReLU when no residual) -> bf16x4 -> LDS [pixel][cout] image
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
                 v[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
             }
         }
-        *reinterpret_cast<u32x4 *>(a.y + off) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + off));
     }
 }
 
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a, int ti
             const int e = tid + it * 256;
             const long long off = pix_off(e / CPP, cout0 + (e % CPP) * 8);
             rres[it] = (u32x4){0u, 0u, 0u, 0u};
-            if (off >= 0) rres[it] = *reinterpret_cast<const u32x4 *>(a.res + off);
+            if (off >= 0) rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + off));
         }
     }
     char *E = smem;
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a, int ti
                 v[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
             }
         }
-        *reinterpret_cast<u32x4 *>(a.y + off) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + off));
     }
 }
 
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(256, 3) void conv_ring32_kernel(ConvArgs a) {
             const int e = tid + it * 256;
             const int m = pix0 + e / CPP, c = cout0 + (e % CPP) * 8;
             rres[it] = (u32x4){0u, 0u, 0u, 0u};
-            if (m < a.M && c < a.Cout) rres[it] = *reinterpret_cast<const u32x4 *>(a.res + out_offset(m, c));
+            if (m < a.M && c < a.Cout) rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + out_offset(m, c)));
         }
     }
     char *E = smem;
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256, 3) void conv_ring32_kernel(ConvArgs a) {
                 v[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
             }
         }
-        *reinterpret_cast<u32x4 *>(a.y + off) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + off));
     }
 }
 
