@@ -73,10 +73,10 @@ def main():
     records = []
     orig_conv2d = nn_ops.conv2d
 
-    def timed_conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0):
+    def timed_conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0, res_upsample=False):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        y = orig_conv2d(x, pc, residual=residual, relu=relu, out=out, variant=variant, c_off=c_off)
+        y = orig_conv2d(x, pc, residual=residual, relu=relu, out=out, variant=variant, c_off=c_off, res_upsample=res_upsample)
         e1.record()
         n, ho, wo, _ = y.shape
         byts = 2.0 * (x.numel() + n * ho * wo * pc.cout + pc.cout * pc.cin_real * pc.kh * pc.kw + (residual.numel() if residual is not None else 0))

@@ -141,6 +141,8 @@ typedef struct md_conv2d_attrs {
      * and channel-concatenated outputs (rpn.py:152, pointpillars.py:598) run on the same MFMA kernel. */
     int32_t adv;
     int32_t pad_top, pad_left, sub_h, sub_w, out_stride, out_off_y, out_off_x, c_off, cout;
+    int32_t res_upsample;        /* 1: `residual` is [N, ceil(Ho/2), ceil(Wo/2), Cout] and is added with nearest 2x
+                                    upsampling (FPN top-down add fused into the lateral conv); plain addressing only */
     int32_t korder;              /* K order of the packed weights: 0 = (kh,kw,ci) [default]; 1 = (ci/64, kh,kw, ci%64)
                                     (needs Cin % 64 == 0): taps innermost, so consecutive K tiles of a 3x3 window
                                     re-read nearly the same activation lines */

@@ -53,6 +53,8 @@ struct ConvArgs {
     int os, oy, ox, c_off;  // output pixel (ho*os + oy, wo*os + ox), channels [c_off, c_off + Cout)
     int adv;                // 0: plain (off = m*Cout + c)
     int korder;             // 0: K = (tap, ci); 1: K = (ci/64, tap, ci%64)  (MODE 2 only)
+    int res_up;             // 1: residual is [N, ceil(Ho/2), ceil(Wo/2), Cout], read with nearest 2x upsampling
+                            //    (the FPN top-down add fused into the lateral 1x1 conv); plain addressing only
 };
 
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((unsigned)v << 16); }
@@ -475,6 +477,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         const int ho = r / a.Wo, wo = r - ho * a.Wo;
         return (((size_t)n * a.Hf + ho * a.os + a.oy) * a.Wf + wo * a.os + a.ox) * a.Ctot + a.c_off + c;
     };
+    auto res_offset = [&](int m, int c) -> size_t {
+        if (!a.res_up) return out_offset(m, c);
+        const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
+        const int ho = r / a.Wo, wo = r - ho * a.Wo;
+        const int Hr = (a.Ho + 1) >> 1, Wr = (a.Wo + 1) >> 1;
+        return (((size_t)n * Hr + (ho >> 1)) * Wr + (wo >> 1)) * a.Cout + c;
+    };
     u32x4 rres[EP_ITERS];
     if (a.res) {
 #pragma unroll
@@ -483,7 +492,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
             const int p_local = e / CPP, cc = e % CPP;
             const int m = pix0 + p_local, c = cout0 + cc * 8;
             rres[it] = (u32x4){0u, 0u, 0u, 0u};
-            if (m < a.M && c < a.Cout) rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + out_offset(m, c)));
+            if (m < a.M && c < a.Cout) rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + res_offset(m, c)));
         }
     }
     // bias (+ReLU when no residual) -> bf16x4 -> LDS [pixel][cout] image
@@ -1010,6 +1019,8 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     if (a.kh < 1 || a.kw < 1 || a.stride < 1 || a.pad < 0 || a.relu < 0 || a.relu > 2) return MD_ERR_ARG;
     a.adv = at->adv != 0;
     a.korder = at->korder;
+    a.res_up = at->res_upsample != 0 && params[3] != nullptr;
+    if (a.res_up && a.adv) return MD_ERR_ARG;
     if (!a.adv) {
         a.Ho = a.Hf; a.Wo = a.Wf; a.Cout = a.Ctot;
         a.pad_top = a.pad_left = a.pad; a.os = 1; a.oy = a.ox = a.c_off = 0;
@@ -1031,7 +1042,10 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     const int cout_pad = (a.Cout + ctile - 1) / ctile * ctile;
     if (a.Kpad % BK || a.Kpad < a.Kreal || shapes[1][0] != cout_pad) return MD_ERR_ARG;
     if (numel(ndims, shapes, 2) != cout_pad) return MD_ERR_ARG;
-    if (params[3] && (ndims[3] != 4 || numel(ndims, shapes, 3) != numel(ndims, shapes, 4))) return MD_ERR_ARG;
+    if (params[3] && !a.res_up && (ndims[3] != 4 || numel(ndims, shapes, 3) != numel(ndims, shapes, 4))) return MD_ERR_ARG;
+    if (a.res_up && (ndims[3] != 4 || shapes[3][0] != a.N || shapes[3][1] != (a.Ho + 1) / 2 || shapes[3][2] != (a.Wo + 1) / 2 ||
+                     shapes[3][3] != a.Cout))
+        return MD_ERR_ARG;
     const long long M = (long long)a.N * a.Ho * a.Wo;
     if (M <= 0) return MD_OK;
     if (!params[0] || !params[4]) return MD_ERR_ARG;
@@ -1052,9 +1066,9 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     // 3x3 / stride 1 / pad 1 with korder-1 weights: halo-reuse kernel (variant 0 auto or 11 forced)
     const bool halo_ok = dma_ok && !a.adv && a.korder == 1 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 &&
                          a.Cin % 64 == 0 && ctile == 128;
-    if (halo_ok && (variant == 0 || variant == 11)) return launch_conv3x3_halo(a, s);
+    if (halo_ok && !a.res_up && (variant == 0 || variant == 11)) return launch_conv3x3_halo(a, s);
     if (variant == 11) variant = 2;
-    if (variant == 12 && fast && ctile == 128) return launch_conv_ring32(a, s);
+    if (variant == 12 && fast && ctile == 128 && !a.res_up) return launch_conv_ring32(a, s);
     if (ctile != 128) {
         if (variant == 1) return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 0>(a, s) : launch_conv<256, 1, 4, 1, 2, 0>(a, s);
         if (fast) return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 2>(a, s) : launch_conv<256, 1, 4, 1, 2, 2>(a, s);

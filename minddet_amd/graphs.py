@@ -173,9 +173,17 @@ class FPN:
         return self
 
     def __call__(self, feats):
-        lats = [l(f) for l, f in zip(self.lateral, feats)]
-        for i in range(len(lats) - 1, 0, -1):
-            lats[i - 1] = nn_ops.upsample_add(lats[i - 1], lats[i])
+        # top-down path: lateral_i + nearest_up(merged_{i+1}).  When the pyramid halves exactly the add is fused into
+        # the lateral 1x1 conv as an upsampled residual (md_conv2d res_upsample); otherwise the streaming kernel runs.
+        lats = [None] * len(feats)
+        lats[-1] = self.lateral[-1](feats[-1])
+        for i in range(len(feats) - 2, -1, -1):
+            h, w = feats[i].shape[1], feats[i].shape[2]
+            top = lats[i + 1]
+            if top.shape[1] == (h + 1) // 2 and top.shape[2] == (w + 1) // 2:
+                lats[i] = nn_ops.conv2d(feats[i], self.lateral[i].packed, residual=top, res_upsample=True)
+            else:
+                lats[i] = nn_ops.upsample_add(self.lateral[i](feats[i]), top)
         outs = [o(l) for o, l in zip(self.output, lats)]
         while len(outs) < self.num_outs:
             outs.append(nn_ops.maxpool2d(outs[-1], 1, 2, 0, zero_pad=False))

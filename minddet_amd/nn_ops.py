@@ -18,7 +18,7 @@ class _ConvAttrs(ctypes.Structure):
                 ("relu", ctypes.c_int32), ("variant", ctypes.c_int32), ("adv", ctypes.c_int32), ("pad_top", ctypes.c_int32),
                 ("pad_left", ctypes.c_int32), ("sub_h", ctypes.c_int32), ("sub_w", ctypes.c_int32),
                 ("out_stride", ctypes.c_int32), ("out_off_y", ctypes.c_int32), ("out_off_x", ctypes.c_int32),
-                ("c_off", ctypes.c_int32), ("cout", ctypes.c_int32), ("korder", ctypes.c_int32)]
+                ("c_off", ctypes.c_int32), ("cout", ctypes.c_int32), ("res_upsample", ctypes.c_int32), ("korder", ctypes.c_int32)]
 
 
 def cout_tile(cout):
@@ -95,7 +95,7 @@ def conv_out_hw(h, w, pc):
 CONV_VARIANT = 0  # 0 auto; 1/2/3 force a kernel variant (A/B measurements, see md_conv2d_attrs)
 
 
-def conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0):
+def conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0, res_upsample=False):
     """x [N,H,W,Cin] bf16 NHWC contiguous CUDA tensor -> y [N,Ho,Wo,Cout] bf16.
     With `out` wider than the layer (channel concat, rpn.py:152) the result goes to channels
     [c_off, c_off + Cout) of `out`."""
@@ -108,6 +108,7 @@ def conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0):
     attrs = _ConvAttrs(pc.kh, pc.kw, pc.stride, pc.pad, int(pc.relu if relu is None else relu),
                        int(CONV_VARIANT if variant is None else variant))
     attrs.korder = getattr(pc, "korder", 0)
+    attrs.res_upsample = int(bool(res_upsample))
     if out.shape[3] != pc.cout or c_off:
         attrs.adv, attrs.pad_top, attrs.pad_left, attrs.sub_h, attrs.sub_w = 1, pc.pad, pc.pad, ho, wo
         attrs.out_stride, attrs.c_off, attrs.cout = 1, int(c_off), pc.cout

@@ -112,3 +112,21 @@ def test_conv_rejects_bad_args():
         nn_ops.conv2d(torch.zeros((1, 8, 8, 32), dtype=torch.bfloat16, device=DEV), pc)
     with pytest.raises(_lib.MindDetHipError):
         nn_ops.conv2d(torch.zeros((1, 8, 8, 64), dtype=torch.float32, device=DEV), pc)
+
+
+def test_conv_fused_upsampled_residual():
+    """FPN top-down add fused into the lateral 1x1 conv: y = conv(x) + nearest_up2(top)."""
+    from minddet_amd import nn_ops
+
+    g = torch.Generator().manual_seed(5)
+    for (h, w) in [(50, 84), (25, 41)]:
+        wt = torch.randn((256, 512, 1, 1), generator=g) * 0.05
+        bias = torch.randn((256,), generator=g) * 0.1
+        pc = nn_ops.pack_conv(wt, bias=bias).to(DEV)
+        x = torch.randn((2, h, w, 512), generator=g).to(torch.bfloat16)
+        top = torch.randn((2, (h + 1) // 2, (w + 1) // 2, 256), generator=g).to(torch.bfloat16)
+        y = nn_ops.conv2d(x.to(DEV), pc, residual=top.to(DEV), res_upsample=True).float().cpu()
+        c = F.conv2d(x.float().permute(0, 3, 1, 2), wt.to(torch.bfloat16).float(), bias).permute(0, 2, 3, 1)
+        up = top.float().repeat_interleave(2, 1).repeat_interleave(2, 2)[:, :h, :w]
+        ref = c.to(torch.bfloat16).float() + up
+        assert ((y - ref).abs() <= 1.5e-2 * ref.abs() + 1.5e-2).all()
