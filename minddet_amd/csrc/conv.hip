@@ -991,6 +991,288 @@ static int launch_conv3x3_halo(ConvArgs &a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// 256(cout) x 256(pixel) x 64 PING-PONG kernel for the MFMA-bound layers (Cin % 64 == 0, Cout % 256 == 0).
+//
+// Why: on the 128x128 kernels a K tile's LDS-DMA batch and its MFMAs do not overlap (r01 ablations) and one
+// barrier per tile drains the DMA queue (vmcnt 0).  Here ONE workgroup of 8 waves owns a CU.  Waves 0-3 (cout rows
+// 0-127) and waves 4-7 (rows 128-255) sit pairwise on the four SIMDs and run HALF A PHASE APART (group 1 passes one
+// extra barrier up front, group 0 one at the end): while one group runs its 8-MFMA cluster at raised priority the
+// other issues its fragment reads and its share of the LDS-DMA.  A K tile is two phases (16 MFMAs = one 64-row half of the
+// wave's 128 x 64 output each) and four half tiles {A0, B0, B1, A1} x two parities = 128 KiB of LDS; the DMA stream
+// runs with COUNTED waits (vmcnt 8 = four half tiles stay in flight across every barrier).
+//
+// Hazard bookkeeping (p = phase index, groups staggered by one barrier; a phase's fragment reads are RETIRED
+// (lgkmcnt 0) before its first barrier):
+//   RAW  a vmcnt wait placed before the first barrier of phase p covers reads issued in phase p+1 by BOTH groups;
+//   WAR  a buffer may be re-staged in phase p when its last ds_read was issued in phase <= p-1.
+//   tile t:  ph0 reads A0,B0,B1 / stages (t+1,A1)      ph1 reads A1 / stages (t+2,A0), (t+2,B0), (t+2,B1)
+//   every DMA is waited for two phases after its issue: vmcnt(8) = the four youngest half tiles stay in flight.
+// Half tile "A0" = cout rows {0-63, 128-191} (the first 64 rows of each wave group), "A1" the others; "B0" = the
+// first 32 pixels of each of the four 64-pixel wave columns, "B1" the others -- so every wave reads every half tile.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int PP_HALF = 128 * ROWB;  // 16 KiB
+struct KWalk { int tap, kh, kw, cc0; };
+
+template <int ABL>  // 0: product; timing ablations (wrong results): 1 no in-loop staging, 2 no output stores, 3 no MFMAs
+__global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
+    constexpr int CT = 256, PT = 256, NT = 512;
+    constexpr int EP_STRIDE = CT * 2 + 16;
+    constexpr unsigned OOR = 0x80000000u;
+    constexpr int H_A0 = 0, H_B0 = 1, H_B1 = 2, H_A1 = 3;
+    typedef __attribute__((address_space(3))) void lds_void;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ct = slot % a.n_ctiles, pt = xcd * a.pt_per_xcd + slot / a.n_ctiles;
+    if (pt >= a.n_ptiles) return;
+    const int cout0 = ct * CT, pix0 = pt * PT;
+    const int n_taps = a.kh * a.kw, nk = a.Kpad / BK;
+
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+
+    // ---- staging map: one wave instruction = 8 rows x 128 B; a half tile = 2 instructions per wave (rows srow, srow+64)
+    const int srow = wave * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((srow >> 1) & 7);  // source-side swizzle (same for srow and srow + 64)
+    const int a_off = ((cout0 + srow) * a.Kpad + chunk * 8) * 2;
+    const int a_half = 64 * a.Kpad * 2, a_pass = 128 * a.Kpad * 2;
+    int p_base[4];       // [hB * 2 + i]: byte offset of (n, hi0, wi0, chunk) of the staged pixel row
+    unsigned p_taps[4];  // tap-validity bits (0 past M)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int hB = q >> 1, i = q & 1;
+        const int m = pix0 + (i * 2 + (wave >> 2)) * 64 + hB * 32 + (wave & 3) * 8 + (lane >> 3);
+        p_base[q] = 0; p_taps[q] = 0u;
+        if (m < a.M) {
+            const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
+            const int ho = r / a.Wo, wo = r - ho * a.Wo;
+            const int hi0 = ho * a.stride - a.pad_top, wi0 = wo * a.stride - a.pad_left;
+            p_base[q] = (((n * a.H + hi0) * a.W + wi0) * a.Cin) * 2 + chunk * 16;
+            unsigned bits = 0u, bit = 1u;
+            for (int dy = 0; dy < a.kh; ++dy)
+                for (int dx = 0; dx < a.kw; ++dx, bit <<= 1)
+                    if ((unsigned)(hi0 + dy) < (unsigned)a.H && (unsigned)(wi0 + dx) < (unsigned)a.W) bits |= bit;
+            p_taps[q] = bits;
+        }
+    }
+    auto walk_next = [&](KWalk &w) {
+        if (a.korder == 0) {
+            w.cc0 += 8;
+            if (w.cc0 == a.cpt) {
+                w.cc0 = 0; ++w.tap;
+                if (++w.kw == a.kw) { w.kw = 0; ++w.kh; }
+            }
+        } else {
+            ++w.tap;
+            if (++w.kw == a.kw) { w.kw = 0; ++w.kh; }
+            if (w.tap == n_taps) { w.tap = 0; w.kh = 0; w.kw = 0; w.cc0 += 8; }
+        }
+    };
+    auto stage_A = [&](int kt, int hA, int hbuf) {
+        if (ABL == 1 && kt >= 2) return;
+        char *dst = smem + ((kt & 1) * 4 + hbuf) * PP_HALF + wave * (8 * ROWB);
+        const unsigned dead = (unsigned)((nk - 1 - kt) >> 31) << 31;  // 2^31 for the tiles past the end: out of range, zero fill
+        const int ktc = kt < nk ? kt : nk - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(dst + i * 64 * ROWB), 16,
+                                                     (int)((unsigned)(a_off + hA * a_half + i * a_pass) | dead), ktc * (BK * 2), 0, 0);
+    };
+    auto stage_B = [&](int kt, int hB, int hbuf, const KWalk &w) {
+        if (ABL == 1 && kt >= 2) return;
+        char *dst = smem + ((kt & 1) * 4 + hbuf) * PP_HALF + wave * (8 * ROWB);
+        const unsigned dead = (unsigned)((nk - 1 - kt) >> 31) << 31;
+        const int soff = ((w.kh * a.W + w.kw) * a.Cin + w.cc0 * 8) * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned voff = ((p_taps[hB * 2 + i] >> (w.tap & 31)) & 1u) ? ((unsigned)(p_base[hB * 2 + i] + soff) | dead) : OOR;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(dst + i * 64 * ROWB), 16, (int)voff, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int lr = lane & 31, lh = lane >> 5;
+    int fa_off[4], fb_off[4];  // per k-step fragment offsets inside a half tile
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        fa_off[kk] = swz(wr * 64 + lr, kk * 2 + lh);
+        fb_off[kk] = swz(wc * 32 + lr, kk * 2 + lh);
+    }
+    bf16x8 fa[2][4], fb[2][4];
+
+    // The accumulators of a phase are threaded through empty volatile asm statements on both sides of its MFMA cluster:
+    // MFMA builtins are pure, and without the pin the optimiser sinks them past the barriers into the next phase's
+    // load section (seen in the ISA), which destroys the ping-pong.
+#define PP_PIN(I0) asm volatile("" : "+v"(acc[I0][0]), "+v"(acc[I0][1]), "+v"(acc[I0 + 1][0]), "+v"(acc[I0 + 1][1]));
+#define PP_SYNC_LOADS(I0)                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        \
+    if (ABL != 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            \
+    __builtin_amdgcn_s_barrier();                                             \
+    PP_PIN(I0)                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                        \
+    __builtin_amdgcn_s_setprio(1);
+#define PP_END_PHASE(I0)                                                      \
+    PP_PIN(I0)                                                                \
+    __builtin_amdgcn_s_setprio(0);                                            \
+    __builtin_amdgcn_sched_barrier(0);                                        \
+    __builtin_amdgcn_s_barrier();                                             \
+    __builtin_amdgcn_sched_barrier(0);
+#define PP_MFMA(I0)                                                                                                  \
+    if (ABL != 3) _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                 \
+        acc[I0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][kk], fb[0][kk], acc[I0][0], 0, 0, 0);             \
+        acc[I0 + 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][kk], fb[0][kk], acc[I0 + 1][0], 0, 0, 0);     \
+        acc[I0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][kk], fb[1][kk], acc[I0][1], 0, 0, 0);             \
+        acc[I0 + 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][kk], fb[1][kk], acc[I0 + 1][1], 0, 0, 0);     \
+    }
+
+    // ---- prologue: tile 0 and the A0/B0/B1 halves of tile 1 (seven half tiles)
+    KWalk w0 = {0, 0, 0, 0}, w1 = w0;
+    walk_next(w1);
+    KWalk w2 = w1;
+    walk_next(w2);
+    stage_A(0, 0, H_A0); stage_B(0, 0, H_B0, w0); stage_B(0, 1, H_B1, w0); stage_A(0, 1, H_A1);
+    stage_A(1, 0, H_A0); stage_B(1, 0, H_B0, w1); stage_B(1, 1, H_B1, w1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs half a phase behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int t = 0; t < nk; ++t) {
+        const char *T = smem + (t & 1) * (4 * PP_HALF);
+        // phase 0: cout rows 0-63 of the wave x its 64 pixels
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fb[0][kk] = *reinterpret_cast<const bf16x8 *>(T + H_B0 * PP_HALF + fb_off[kk]);
+            fb[1][kk] = *reinterpret_cast<const bf16x8 *>(T + H_B1 * PP_HALF + fb_off[kk]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fa[0][kk] = *reinterpret_cast<const bf16x8 *>(T + H_A0 * PP_HALF + fa_off[kk]);
+            fa[1][kk] = *reinterpret_cast<const bf16x8 *>(T + H_A0 * PP_HALF + fa_off[kk] + 32 * ROWB);
+        }
+        stage_A(t + 1, 1, H_A1);
+        PP_SYNC_LOADS(0)
+        PP_MFMA(0)
+        PP_END_PHASE(0)
+        // phase 1: cout rows 64-127
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fa[0][kk] = *reinterpret_cast<const bf16x8 *>(T + H_A1 * PP_HALF + fa_off[kk]);
+            fa[1][kk] = *reinterpret_cast<const bf16x8 *>(T + H_A1 * PP_HALF + fa_off[kk] + 32 * ROWB);
+        }
+        stage_A(t + 2, 0, H_A0); stage_B(t + 2, 0, H_B0, w2); stage_B(t + 2, 1, H_B1, w2);
+        PP_SYNC_LOADS(2)
+        PP_MFMA(2)
+        PP_END_PHASE(2)
+        walk_next(w2);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // every wave has now passed 2 + 4 nk barriers
+#undef PP_PIN
+#undef PP_SYNC_LOADS
+#undef PP_END_PHASE
+#undef PP_MFMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero-fill DMAs of the two tiles past the end
+    __syncthreads();
+
+    // ---- epilogue: bias (+act) -> bf16x4 -> LDS [pixel][cout] -> (+residual, ReLU) -> 16-B NHWC stores
+    constexpr int CPP = CT / 8, EP_ITERS = PT * CPP / NT;
+    char *E = smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c_local = wr * 128 + i * 32 + 8 * g + 4 * lh;
+            const float4 bv = *reinterpret_cast<const float4 *>(a.bias + cout0 + c_local);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p_local = wc * 64 + j * 32 + lr;
+                float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
+                float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
+                if (a.relu == 1 && !a.res) {
+                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                } else if (a.relu == 2) {
+                    v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
+                }
+                uint2 pk;
+                pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+                pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
+            }
+        }
+    }
+    __syncthreads();
+    auto out_offset = [&](int m, int c) -> size_t {
+        if (!a.adv) return (size_t)m * a.Cout + c;
+        const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
+        const int ho = r / a.Wo, wo = r - ho * a.Wo;
+        return (((size_t)n * a.Hf + ho * a.os + a.oy) * a.Wf + wo * a.os + a.ox) * a.Ctot + a.c_off + c;
+    };
+    auto res_offset = [&](int m, int c) -> size_t {
+        if (!a.res_up) return out_offset(m, c);
+        const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
+        const int ho = r / a.Wo, wo = r - ho * a.Wo;
+        const int Hr = (a.Ho + 1) >> 1, Wr = (a.Wo + 1) >> 1;
+        return (((size_t)n * Hr + (ho >> 1)) * Wr + (wo >> 1)) * a.Cout + c;
+    };
+    u32x4 rres[EP_ITERS];
+    if (a.res) {
+#pragma unroll
+        for (int it = 0; it < EP_ITERS; ++it) {
+            const int e = tid + it * NT;
+            const int m = pix0 + e / CPP, c = cout0 + (e % CPP) * 8;
+            rres[it] = (u32x4){0u, 0u, 0u, 0u};
+            if (m < a.M) rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + res_offset(m, c)));
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < EP_ITERS; ++it) {
+        const int e = tid + it * NT;
+        const int p_local = e / CPP, cc = e % CPP;
+        const int m = pix0 + p_local, c = cout0 + cc * 8;
+        if (m >= a.M) continue;
+        u32x4 v = *reinterpret_cast<const u32x4 *>(E + p_local * EP_STRIDE + cc * 16);
+        if (a.res) {
+            const u32x4 rv = rres[it];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float lo = bf2f((uint16_t)(v[k] & 0xffff)) + bf2f((uint16_t)(rv[k] & 0xffff));
+                float hi = bf2f((uint16_t)(v[k] >> 16)) + bf2f((uint16_t)(rv[k] >> 16));
+                if (a.relu == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                v[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+            }
+        }
+        if (ABL == 2 && v[0] != 0x12345u) continue;
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + out_offset(m, c)));
+    }
+}
+
+template <int ABL = 0>
+static int launch_conv_pingpong(ConvArgs &a, hipStream_t s) {
+    a.n_ctiles = a.Cout / 256;
+    a.n_ptiles = (a.M + 255) / 256;
+    a.pt_per_xcd = (a.n_ptiles + 7) / 8;
+    const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
+    if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
+    const int lds = 256 * (256 * 2 + 16);  // 135,168 B: the epilogue image (>= the 128 KiB of staging buffers)
+    if (hipFuncSetAttribute((const void *)conv_pingpong_kernel<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return MD_ERR_HIP;
+    hipLaunchKernelGGL(conv_pingpong_kernel<ABL>, dim3((unsigned)blocks), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
+}
+
 }  // namespace md
 
 using namespace md;
@@ -1066,8 +1348,15 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     // 3x3 / stride 1 / pad 1 with korder-1 weights: halo-reuse kernel (variant 0 auto or 11 forced)
     const bool halo_ok = dma_ok && !a.adv && a.korder == 1 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 &&
                          a.Cin % 64 == 0 && ctile == 128;
+    // MFMA-bound layers (K >= 1024, Cout a multiple of 256): the 256x256 ping-pong kernel (measured r01, tools/conv_ab.py:
+    // +17 % over the halo kernel on 3x3 256->256, +75 % on the 12544->1024 FC; loses on the HBM-bound K < 1024 layers)
+    const bool pp_ok = fast && dma_ok && a.Cout % 256 == 0 && a.Kpad >= 1024 && M >= 8192;
+    if (variant == 0 && pp_ok) return launch_conv_pingpong<0>(a, s);
     if (halo_ok && !a.res_up && (variant == 0 || variant == 11)) return launch_conv3x3_halo(a, s);
     if (variant == 11) variant = 2;
+    if (variant == 15 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0>(a, s);  // 256x256 ping-pong, 8 waves
+    if (variant >= 17 && variant <= 19 && fast && dma_ok && a.Cout % 256 == 0)                       // timing ablations
+        return variant == 17 ? launch_conv_pingpong<1>(a, s) : (variant == 18 ? launch_conv_pingpong<2>(a, s) : launch_conv_pingpong<3>(a, s));
     if (variant == 12 && fast && ctile == 128 && !a.res_up) return launch_conv_ring32(a, s);
     if (ctile != 128) {
         if (variant == 1) return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 0>(a, s) : launch_conv<256, 1, 4, 1, 2, 0>(a, s);

@@ -29,7 +29,7 @@ for (H, W, Cin, Cout, k, s, res) in LAYERS:
     ho, wo = nn_ops.conv_out_hw(H, W, pc)
     r = torch.randn((n, ho, wo, pc.cout), generator=g).to(torch.bfloat16).to(dev) if res else None
     fl = 2.0 * n * ho * wo * Cout * Cin * k * k
-    variants = [2, 13, 14, 111] if nn_ops.cout_tile(pc.cout) == 128 else [1, 2]
+    variants = [2, 111, 115, 117] if nn_ops.cout_tile(pc.cout) == 128 else [1, 2]
     outs, times = {}, {v: [] for v in variants}
     def run(v):
         if v >= 100:
