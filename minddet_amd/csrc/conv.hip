@@ -53,6 +53,7 @@ struct ConvArgs {
     int os, oy, ox, c_off;  // output pixel (ho*os + oy, wo*os + ox), channels [c_off, c_off + Cout)
     int adv;                // 0: plain (off = m*Cout + c)
     int korder;             // 0: K = (tap, ci); 1: K = (ci/64, tap, ci%64)  (MODE 2 only)
+    int single_buf;         // PIPE 0 LDS-DMA loop with ONE staging buffer (short-K layers: more workgroups per CU)
     int res_up;             // 1: residual is [N, ceil(Ho/2), ceil(Wo/2), Cout], read with nearest 2x upsampling
                             //    (the FPN top-down add fused into the lateral 1x1 conv); plain addressing only
 };
@@ -446,6 +447,17 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         __syncthreads();
     } else
     if constexpr (GLDS) {
+        if (a.single_buf) {
+            // short-K, HBM/latency-bound layers: half the LDS -> twice the resident workgroups, whose epilogues
+            // (residual loads, stores) then overlap each other's loops
+            for (int kt = 0; kt < nk; ++kt) {
+                dma_tile(kt, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                compute_tile(0);
+                __syncthreads();
+            }
+        } else {
         dma_tile(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
             // tile kt has landed (every wave waits for its own DMAs, the barrier publishes them) and every
@@ -456,6 +468,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
             compute_tile(kt & 1);
         }
         __syncthreads();
+        }
     } else {
         load_tile(0);
         store_tile(0);
@@ -574,7 +587,8 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
     a.n_ptiles = (a.M + PT - 1) / PT;
     // one staging buffer is enough when the whole K fits one tile (1x1 convs on 64 channels): more
     // workgroups per CU for the HBM-bound layers
-    const int nbuf = PIPE == 2 ? 4 : (PIPE == 1 ? 3 : (a.Kpad / BK > 1 ? 2 : 1));
+    if (PIPE != 0 || MODE == 0) a.single_buf = 0;
+    const int nbuf = PIPE == 2 ? 4 : (PIPE == 1 ? 3 : (a.Kpad / BK > 1 && !a.single_buf ? 2 : 1));
     const int tile_bytes = (CT + PT) * ROWB * nbuf;
     constexpr int ep_bytes = PT * (CT * 2 + 16);
     const int lds = tile_bytes > ep_bytes ? tile_bytes : ep_bytes;
@@ -1289,6 +1303,7 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
         return MD_ERR_ARG;
     if (!ndims || !shapes || ndims[0] != 4 || ndims[1] != 2 || ndims[4] != 4) return MD_ERR_ARG;
     const md_conv2d_attrs *at = (const md_conv2d_attrs *)extra;
+    int variant_override = -1;
     ConvArgs a;
     a.x = (const uint16_t *)params[0];
     a.w = (const uint16_t *)params[1];
@@ -1302,6 +1317,10 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     a.adv = at->adv != 0;
     a.korder = at->korder;
     a.res_up = at->res_upsample != 0 && params[3] != nullptr;
+    // one LDS staging buffer by default: measured r01 (tools/conv_ab.py), 4 resident workgroups per CU with a serial
+    // DMA -> MFMA loop beat 2 double-buffered ones on every benchmark layer (+8...43 %); variant 2 keeps the double buffer
+    a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 21;
+    if (at->variant == 20) variant_override = 2;
     if (a.res_up && a.adv) return MD_ERR_ARG;
     if (!a.adv) {
         a.Ho = a.Hf; a.Wo = a.Wf; a.Cout = a.Ctot;
@@ -1337,7 +1356,7 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     a.cpt = a.Cin / 8;
     hipStream_t s = (hipStream_t)stream;
     // variant: 0 = auto; 1 = register-staged 128x128; 2 = LDS-DMA 128x128; 3 = LDS-DMA 256(cout)x256(pix), 8 waves
-    int variant = at->variant;
+    int variant = variant_override >= 0 ? variant_override : at->variant;
     const long long x_bytes = (long long)a.N * a.H * a.W * a.Cin * 2, w_bytes = (long long)cout_pad * a.Kpad * 2;
     const bool dma_ok = x_bytes < 0x7fff0000LL && w_bytes < 0x7fff0000LL;  // 32-bit DMA offsets, out-of-range marker 2^31
     a.x_bytes = (unsigned)(dma_ok ? x_bytes : 0);
@@ -1352,7 +1371,7 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     // +17 % over the halo kernel on 3x3 256->256, +75 % on the 12544->1024 FC; loses on the HBM-bound K < 1024 layers)
     const bool pp_ok = fast && dma_ok && a.Cout % 256 == 0 && a.Kpad >= 1024 && M >= 8192;
     if (variant == 0 && pp_ok) return launch_conv_pingpong<0>(a, s);
-    if (halo_ok && !a.res_up && (variant == 0 || variant == 11)) return launch_conv3x3_halo(a, s);
+    if (halo_ok && !a.res_up && variant == 11) return launch_conv3x3_halo(a, s);  // superseded by the two paths around it
     if (variant == 11) variant = 2;
     if (variant == 15 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0>(a, s);  // 256x256 ping-pong, 8 waves
     if (variant >= 17 && variant <= 19 && fast && dma_ok && a.Cout % 256 == 0)                       // timing ablations
@@ -1364,6 +1383,7 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
         return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 1>(a, s) : launch_conv<256, 1, 4, 1, 2, 1>(a, s);
     }
     const bool can256 = cout_pad % 256 == 0;
+    if (variant == 21 && fast) return launch_conv<256, 2, 2, 2, 1, 2>(a, s);  // 128(cout) x 64(pix), single buffer
     if (variant == 13 && fast && ctile == 128) return launch_conv<256, 2, 2, 2, 2, 2, 3>(a, s);           // 128x128, interleaved DMA issue
     if (variant == 14 && fast && ctile == 128 && can256) return launch_conv<512, 2, 4, 4, 2, 2, 3>(a, s);  // 256x256, interleaved
     if (variant == 0) variant = 2;  // measured (tools/conv_ab.py, r01): the 128x128 LDS-DMA kernel at 2 workgroups/CU beats
