@@ -1029,7 +1029,9 @@ static int launch_conv3x3_halo(ConvArgs &a, hipStream_t s) {
 constexpr int PP_HALF = 128 * ROWB;  // 16 KiB
 struct KWalk { int tap, kh, kw, cc0; };
 
-template <int ABL>  // 0: product; timing ablations (wrong results): 1 no in-loop staging, 2 no output stores, 3 no MFMAs
+// MF 0: v_mfma_f32_32x32x16_bf16, MF 1: v_mfma_f32_16x16x32_bf16 (same LDS image, reads and cycles per flop; the chip holds a
+// different clock on the two shapes under load -- MI355X_MICROARCH.md DVFS item 7 -- so both are built and the faster kept).
+template <int ABL, int MF = 0>  // ABL 0: product; timing ablations (wrong results): 1 no in-loop staging, 2 no output stores, 4 stamps
 __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     constexpr int CT = 256, PT = 256, NT = 512;
     constexpr int EP_STRIDE = CT * 2 + 16;
@@ -1109,47 +1111,80 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         }
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[MF ? 1 : 4][MF ? 1 : 2];
+    f32x4 acc4[MF ? 8 : 1][MF ? 4 : 1];  // MF 1: [16-row fragment of the wave's 128 couts][16-pixel fragment of its 64 pixels]
+    if constexpr (MF == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc4[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     const int lr = lane & 31, lh = lane >> 5;
-    int fa_off[4], fb_off[4];  // per k-step fragment offsets inside a half tile
+    const int l16 = lane & 15, lq = lane >> 4;
+    int fa_off[4], fb_off[4];  // per k-step fragment offsets inside a half tile (MF 1 uses two: K 32 per step)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        fa_off[kk] = swz(wr * 64 + lr, kk * 2 + lh);
-        fb_off[kk] = swz(wc * 32 + lr, kk * 2 + lh);
+        fa_off[kk] = MF ? swz(wr * 64 + l16, (kk & 1) * 4 + lq) : swz(wr * 64 + lr, kk * 2 + lh);
+        fb_off[kk] = MF ? swz(wc * 32 + l16, (kk & 1) * 4 + lq) : swz(wc * 32 + lr, kk * 2 + lh);
     }
+    // operand registers of a phase: MF 0 fa[row fragment 0-1][k step 0-3], fb[pixel half][k step];
+    //                               MF 1 fa[r][s] = row fragment (2r + (s >> 1)), k step (s & 1); fb[h][s] likewise per pixel half
     bf16x8 fa[2][4], fb[2][4];
+    unsigned long long st[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, keep[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // ABL 4: s_memtime stamps of K tile nk/2
+#define PP_STAMP(I) if (ABL == 4) { __builtin_amdgcn_sched_barrier(0); st[I] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 
     // The accumulators of a phase are threaded through empty volatile asm statements on both sides of its MFMA cluster:
     // MFMA builtins are pure, and without the pin the optimiser sinks them past the barriers into the next phase's
     // load section (seen in the ISA), which destroys the ping-pong.
-#define PP_PIN(I0) asm volatile("" : "+v"(acc[I0][0]), "+v"(acc[I0][1]), "+v"(acc[I0 + 1][0]), "+v"(acc[I0 + 1][1]));
+#define PP_PIN(I0)                                                                                                  \
+    if constexpr (MF == 0) {                                                                                        \
+        asm volatile("" : "+v"(acc[I0][0]), "+v"(acc[I0][1]), "+v"(acc[I0 + 1][0]), "+v"(acc[I0 + 1][1]));          \
+    } else {                                                                                                        \
+        asm volatile("" : "+v"(acc4[2 * (I0)][0]), "+v"(acc4[2 * (I0)][1]), "+v"(acc4[2 * (I0)][2]), "+v"(acc4[2 * (I0)][3]),                 \
+                          "+v"(acc4[2 * (I0) + 1][0]), "+v"(acc4[2 * (I0) + 1][1]), "+v"(acc4[2 * (I0) + 1][2]), "+v"(acc4[2 * (I0) + 1][3]), \
+                          "+v"(acc4[2 * (I0) + 2][0]), "+v"(acc4[2 * (I0) + 2][1]), "+v"(acc4[2 * (I0) + 2][2]), "+v"(acc4[2 * (I0) + 2][3]), \
+                          "+v"(acc4[2 * (I0) + 3][0]), "+v"(acc4[2 * (I0) + 3][1]), "+v"(acc4[2 * (I0) + 3][2]), "+v"(acc4[2 * (I0) + 3][3])); \
+    }
 #define PP_SYNC_LOADS(I0)                                                     \
     __builtin_amdgcn_sched_barrier(0);                                        \
+    PP_STAMP((I0) * 5 / 2 + 1)                                                \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        \
     if (ABL != 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            \
+    PP_STAMP((I0) * 5 / 2 + 2)                                                \
     __builtin_amdgcn_s_barrier();                                             \
+    PP_STAMP((I0) * 5 / 2 + 3)                                                \
     PP_PIN(I0)                                                                \
     __builtin_amdgcn_sched_barrier(0);                                        \
     __builtin_amdgcn_s_setprio(1);
 #define PP_END_PHASE(I0)                                                      \
     PP_PIN(I0)                                                                \
     __builtin_amdgcn_s_setprio(0);                                            \
+    PP_STAMP((I0) * 5 / 2 + 4)                                                \
     __builtin_amdgcn_sched_barrier(0);                                        \
     __builtin_amdgcn_s_barrier();                                             \
     __builtin_amdgcn_sched_barrier(0);
 #define PP_MFMA(I0)                                                                                                  \
-    if (ABL != 3) _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                 \
-        acc[I0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][kk], fb[0][kk], acc[I0][0], 0, 0, 0);             \
-        acc[I0 + 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][kk], fb[0][kk], acc[I0 + 1][0], 0, 0, 0);     \
-        acc[I0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][kk], fb[1][kk], acc[I0][1], 0, 0, 0);             \
-        acc[I0 + 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][kk], fb[1][kk], acc[I0 + 1][1], 0, 0, 0);     \
+    if constexpr (MF == 0) {                                                                                         \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                           \
+            acc[I0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][kk], fb[0][kk], acc[I0][0], 0, 0, 0);         \
+            acc[I0 + 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][kk], fb[0][kk], acc[I0 + 1][0], 0, 0, 0); \
+            acc[I0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][kk], fb[1][kk], acc[I0][1], 0, 0, 0);         \
+            acc[I0 + 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][kk], fb[1][kk], acc[I0 + 1][1], 0, 0, 0); \
+        }                                                                                                            \
+    } else {                                                                                                         \
+        _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                \
+            acc4[2 * (I0) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i >> 1][(i & 1) * 2 + k2], fb[j >> 1][(j & 1) * 2 + k2], \
+                                                                            acc4[2 * (I0) + i][j], 0, 0, 0);         \
     }
 
     // ---- prologue: tile 0 and the A0/B0/B1 halves of tile 1 (seven half tiles)
@@ -1164,36 +1199,48 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs half a phase behind group 0
     __builtin_amdgcn_sched_barrier(0);
 
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (ABL == 4) { clk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     for (int t = 0; t < nk; ++t) {
         const char *T = smem + (t & 1) * (4 * PP_HALF);
+        PP_STAMP(0)
         // phase 0: cout rows 0-63 of the wave x its 64 pixels
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            fb[0][kk] = *reinterpret_cast<const bf16x8 *>(T + H_B0 * PP_HALF + fb_off[kk]);
-            fb[1][kk] = *reinterpret_cast<const bf16x8 *>(T + H_B1 * PP_HALF + fb_off[kk]);
+            fb[0][kk] = *reinterpret_cast<const bf16x8 *>(T + H_B0 * PP_HALF + fb_off[kk] + (MF ? (kk >> 1) * 16 * ROWB : 0));
+            fb[1][kk] = *reinterpret_cast<const bf16x8 *>(T + H_B1 * PP_HALF + fb_off[kk] + (MF ? (kk >> 1) * 16 * ROWB : 0));
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            fa[0][kk] = *reinterpret_cast<const bf16x8 *>(T + H_A0 * PP_HALF + fa_off[kk]);
-            fa[1][kk] = *reinterpret_cast<const bf16x8 *>(T + H_A0 * PP_HALF + fa_off[kk] + 32 * ROWB);
+            fa[0][kk] = *reinterpret_cast<const bf16x8 *>(T + H_A0 * PP_HALF + fa_off[kk] + (MF ? (kk >> 1) * 16 * ROWB : 0));
+            fa[1][kk] = *reinterpret_cast<const bf16x8 *>(T + H_A0 * PP_HALF + fa_off[kk] + 32 * ROWB + (MF ? (kk >> 1) * 16 * ROWB : 0));
         }
         stage_A(t + 1, 1, H_A1);
         PP_SYNC_LOADS(0)
         PP_MFMA(0)
         PP_END_PHASE(0)
+        PP_STAMP(5)
         // phase 1: cout rows 64-127
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            fa[0][kk] = *reinterpret_cast<const bf16x8 *>(T + H_A1 * PP_HALF + fa_off[kk]);
-            fa[1][kk] = *reinterpret_cast<const bf16x8 *>(T + H_A1 * PP_HALF + fa_off[kk] + 32 * ROWB);
+            fa[0][kk] = *reinterpret_cast<const bf16x8 *>(T + H_A1 * PP_HALF + fa_off[kk] + (MF ? (kk >> 1) * 16 * ROWB : 0));
+            fa[1][kk] = *reinterpret_cast<const bf16x8 *>(T + H_A1 * PP_HALF + fa_off[kk] + 32 * ROWB + (MF ? (kk >> 1) * 16 * ROWB : 0));
         }
         stage_A(t + 2, 0, H_A0); stage_B(t + 2, 0, H_B0, w2); stage_B(t + 2, 1, H_B1, w2);
         PP_SYNC_LOADS(2)
         PP_MFMA(2)
         PP_END_PHASE(2)
+        PP_STAMP(10)
+        if (ABL == 4 && t == nk / 2) {
+#pragma unroll
+            for (int i = 0; i < 11; ++i) keep[i] = st[i];
+        }
         walk_next(w2);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();  // every wave has now passed 2 + 4 nk barriers
+    unsigned long long clk1 = 0, rt1 = 0;
+    if (ABL == 4) { clk1 = __builtin_readcyclecounter(); rt1 = __builtin_amdgcn_s_memrealtime(); }
+#undef PP_STAMP
 #undef PP_PIN
 #undef PP_SYNC_LOADS
 #undef PP_END_PHASE
@@ -1204,6 +1251,27 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     // ---- epilogue: bias (+act) -> bf16x4 -> LDS [pixel][cout] -> (+residual, ReLU) -> 16-B NHWC stores
     constexpr int CPP = CT / 8, EP_ITERS = PT * CPP / NT;
     char *E = smem;
+    if constexpr (MF == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c_local = wr * 128 + i * 16 + 4 * lq;  // 4 consecutive couts
+            const float4 bv = *reinterpret_cast<const float4 *>(a.bias + cout0 + c_local);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p_local = wc * 64 + j * 16 + l16;
+                float v0 = acc4[i][j][0] + bv.x, v1 = acc4[i][j][1] + bv.y, v2 = acc4[i][j][2] + bv.z, v3 = acc4[i][j][3] + bv.w;
+                if (a.relu == 1 && !a.res) {
+                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                } else if (a.relu == 2) {
+                    v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
+                }
+                uint2 pk;
+                pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+                pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
+            }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -1271,9 +1339,17 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         if (ABL == 2 && v[0] != 0x12345u) continue;
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + out_offset(m, c)));
     }
+    if (ABL == 4 && blockIdx.x == 0) {  // diagnostic build only: the stamps overwrite the first output pixels
+        __syncthreads();
+        if (lane == 0) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(a.y) + wave * 16;
+            for (int i = 0; i < 11; ++i) dbg[i] = keep[i];
+            dbg[11] = clk1 - clk0; dbg[12] = rt1 - rt0;
+        }
+    }
 }
 
-template <int ABL = 0>
+template <int ABL = 0, int MF = 0>
 static int launch_conv_pingpong(ConvArgs &a, hipStream_t s) {
     a.n_ctiles = a.Cout / 256;
     a.n_ptiles = (a.M + 255) / 256;
@@ -1281,9 +1357,9 @@ static int launch_conv_pingpong(ConvArgs &a, hipStream_t s) {
     const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
     const int lds = 256 * (256 * 2 + 16);  // 135,168 B: the epilogue image (>= the 128 KiB of staging buffers)
-    if (hipFuncSetAttribute((const void *)conv_pingpong_kernel<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void *)conv_pingpong_kernel<ABL, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MD_ERR_HIP;
-    hipLaunchKernelGGL(conv_pingpong_kernel<ABL>, dim3((unsigned)blocks), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv_pingpong_kernel<ABL, MF>), dim3((unsigned)blocks), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
@@ -1369,13 +1445,18 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
                          a.Cin % 64 == 0 && ctile == 128;
     // MFMA-bound layers (K >= 1024, Cout a multiple of 256): the 256x256 ping-pong kernel (measured r01, tools/conv_ab.py:
     // +17 % over the halo kernel on 3x3 256->256, +75 % on the 12544->1024 FC; loses on the HBM-bound K < 1024 layers)
-    const bool pp_ok = fast && dma_ok && a.Cout % 256 == 0 && a.Kpad >= 1024 && M >= 8192;
+    // and it needs enough 256x256 tiles to occupy the chip: one workgroup per CU, so compare whole rounds of 256
+    // ping-pong tiles (at ~1.2x the per-CU rate) with rounds of 1024 resident 128x128 tiles
+    const long long pp_blocks = (M + 255) / 256 * (a.Cout / 256), sb_blocks = (M + 127) / 128 * ((a.Cout + 127) / 128);
+    const bool pp_ok = fast && dma_ok && a.Cout % 256 == 0 && a.Kpad >= 1024 && pp_blocks >= 128 &&
+                       (pp_blocks + 255) / 256 * 10 <= (sb_blocks + 1023) / 1024 * 12;
     if (variant == 0 && pp_ok) return launch_conv_pingpong<0>(a, s);
     if (halo_ok && !a.res_up && variant == 11) return launch_conv3x3_halo(a, s);  // superseded by the two paths around it
     if (variant == 11) variant = 2;
     if (variant == 15 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0>(a, s);  // 256x256 ping-pong, 8 waves
+    if (variant == 22 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0, 1>(a, s);  // same, 16x16x32 MFMA
     if (variant >= 17 && variant <= 19 && fast && dma_ok && a.Cout % 256 == 0)                       // timing ablations
-        return variant == 17 ? launch_conv_pingpong<1>(a, s) : (variant == 18 ? launch_conv_pingpong<2>(a, s) : launch_conv_pingpong<3>(a, s));
+        return variant == 17 ? launch_conv_pingpong<1>(a, s) : (variant == 18 ? launch_conv_pingpong<2>(a, s) : launch_conv_pingpong<4>(a, s));
     if (variant == 12 && fast && ctile == 128 && !a.res_up) return launch_conv_ring32(a, s);
     if (ctile != 128) {
         if (variant == 1) return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 0>(a, s) : launch_conv<256, 1, 4, 1, 2, 0>(a, s);
