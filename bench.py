@@ -72,6 +72,10 @@ def main():
     # ---- per-conv event instrumentation (roofline of the dominant kernel)
     records = []
     orig_conv2d = nn_ops.conv2d
+    from minddet_amd import _lib
+    last_kernel = _lib.lib().md_conv2d_last_kernel
+    KNAMES = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<128x128>", 3: "conv_igemm_kernel<small cout>",
+              4: "conv_igemm_kernel<generic K>", 5: "conv3x3_halo_kernel", 6: "conv variant"}
 
     def timed_conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0, res_upsample=False):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -80,7 +84,8 @@ def main():
         e1.record()
         n, ho, wo, _ = y.shape
         byts = 2.0 * (x.numel() + n * ho * wo * pc.cout + pc.cout * pc.cin_real * pc.kh * pc.kw + (residual.numel() if residual is not None else 0))
-        records.append((e0, e1, 2.0 * n * ho * wo * pc.cout * pc.cin_real * pc.kh * pc.kw, tuple(x.shape), pc.cout, pc.kh, byts))
+        records.append((e0, e1, 2.0 * n * ho * wo * pc.cout * pc.cin_real * pc.kh * pc.kw, tuple(x.shape), pc.cout, pc.kh, byts,
+                        last_kernel()))
         return y
 
     def step():
@@ -112,30 +117,52 @@ def main():
 
     roofline = None
     if instrument and records:
-        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in records)
+        ms = [e0.elapsed_time(e1) for e0, e1, *_ in records]
+        tot_ms = sum(ms)
         tot_fl = sum(r[2] for r in records)
-        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        # per kernel; the DOMINANT one (most time) fills the contract fields, the whole conv/FC set goes to "all_conv"
+        per_k = {}
+        for r, t_ms in zip(records, ms):
+            d = per_k.setdefault(r[7], [0.0, 0.0, 0.0, 0])
+            d[0] += t_ms; d[1] += r[2]; d[2] += r[6]; d[3] += 1
+        dom = max(per_k, key=lambda k_: per_k[k_][0])
+        d_ms, d_fl, d_by, d_n = per_k[dom]
+        ach = d_fl / (d_ms * 1e-3) / 1e12
         # layer-wise roofline: each launch is bounded by max(flops / MFMA peak, algorithmic bytes / HBM peak)
         t_roof_ms = sum(max(r[2] / (PEAK_BF16_TFLOPS * 1e12), r[6] / PEAK_HBM_BPS) for r in records) * 1e3
-        traffic = None
+        traffic = all_traffic = None
         tp = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
         if os.path.exists(tp):  # PMC passes are separate rocprofv3 runs (tools/pmc_traffic.py); same config only
             tj = json.load(open(tp))
             if tj.get("batch_per_gpu") == B and type(model).__name__ == "FasterRCNN":
-                traffic = round(tj["hbm_bytes_per_launch"] / 1e6, 2)
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel + conv3x3_halo_kernel (every conv/FC launch of the step)",
+                all_traffic = round(tj["hbm_bytes_per_launch"] / 1e6, 2)
+                bk = tj.get("by_kernel", {}).get(KNAMES.get(dom, "").split("<")[0])
+                if bk and dom == 1:
+                    traffic = round(bk["hbm_bytes_per_launch"] / 1e6, 2)
+        roofline = {"bound": "mfma", "kernel": KNAMES.get(dom, str(dom)) + " (dominant kernel: %.0f %% of the conv/FC time)" % (100 * d_ms / tot_ms),
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                     "traffic": traffic, "traffic_unit": "MB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_conv_traffic.json)",
-                    "algorithmic_mb_per_launch": round(sum(r[6] for r in records) / len(records) / 1e6, 2),
-                    "frac_of_layerwise_roofline": round(t_roof_ms / tot_ms, 4),
-                    "launches_per_step": len(records) // max(args.steps, 1),
-                    "avg_launch_us": round(tot_ms * 1e3 / len(records), 2),
-                    "conv_ms_per_step": round(tot_ms / max(args.steps, 1), 3),
-                    "algorithmic_gflop_per_step": round(tot_fl / max(args.steps, 1) / 1e9, 1)}
+                    "algorithmic_mb_per_launch": round(d_by / d_n / 1e6, 2),
+                    "algorithmic_gflop_per_launch": round(d_fl / d_n / 1e9, 1),
+                    "launches_per_step": d_n // max(args.steps, 1),
+                    "avg_launch_us": round(d_ms * 1e3 / d_n, 2),
+                    "all_conv": {"kernels": {KNAMES.get(k_, str(k_)): {"ms_per_step": round(v[0] / max(args.steps, 1), 3),
+                                                                       "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1),
+                                                                       "launches_per_step": v[3] // max(args.steps, 1)}
+                                             for k_, v in sorted(per_k.items())},
+                                 "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                 "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                 "frac_of_layerwise_roofline": round(t_roof_ms / tot_ms, 4),
+                                 "traffic_mb_per_launch": all_traffic,
+                                 "algorithmic_mb_per_launch": round(sum(r[6] for r in records) / len(records) / 1e6, 2),
+                                 "launches_per_step": len(records) // max(args.steps, 1),
+                                 "avg_launch_us": round(tot_ms * 1e3 / len(records), 2),
+                                 "conv_ms_per_step": round(tot_ms / max(args.steps, 1), 3),
+                                 "algorithmic_gflop_per_step": round(tot_fl / max(args.steps, 1) / 1e9, 1)}}
 
     if args.dump_convs and rank == 0 and records:
         per = {}
-        for e0, e1, fl, xs, cout, k, _b in records:
+        for e0, e1, fl, xs, cout, k, _b, _kid in records:
             key = f"{xs}->{cout} k{k}"
             d = per.setdefault(key, [0.0, 0.0, 0])
             d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += 1

@@ -160,6 +160,19 @@ int md_conv2d(MD_AOT_ARGS);
  * pads Cout up to a multiple of it.  Pure function, callable without a GPU. */
 int md_conv2d_cout_tile(int cout);
 
+/* Which kernel the dispatcher launched for the calling host thread's most recent md_conv2d (0 before any call, or when
+ * the call returned without launching).  Diagnostic only: lets bench.py attribute per-launch HIP-event timings. */
+enum {
+    MD_CONV_KERNEL_NONE = 0,
+    MD_CONV_KERNEL_PINGPONG = 1,        /* conv_pingpong_kernel: 256x256x64, 8 waves, MFMA-bound layers */
+    MD_CONV_KERNEL_IGEMM_128 = 2,       /* conv_igemm_kernel 128x128, LDS-DMA, Cin % 64 == 0 */
+    MD_CONV_KERNEL_IGEMM_SMALL_COUT = 3,/* conv_igemm_kernel 64- / 32-cout tiles */
+    MD_CONV_KERNEL_IGEMM_GENERIC_K = 4, /* conv_igemm_kernel generic K walk (the 7x7 stem) */
+    MD_CONV_KERNEL_HALO = 5,            /* conv3x3_halo_kernel (variant 11) */
+    MD_CONV_KERNEL_OTHER = 6            /* A/B variants */
+};
+int md_conv2d_last_kernel(void);
+
 /* ------------------------------------------------------------------------------------------
  * Streaming NHWC bf16 helpers between convs
  * ------------------------------------------------------------------------------------------ */

@@ -74,6 +74,10 @@ constexpr int ROWB = BK * 2;  // bytes per LDS tile row
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// id of the kernel the dispatcher chose for this host thread's last md_conv2d call (md_conv2d_last_kernel): lets a
+// profiler-less caller (bench.py) attribute per-launch timings to kernels
+static thread_local int g_last_kernel = 0;
+
 // 16 zero bytes: the source of every out-of-image / past-K chunk when staging with LDS-DMA
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
@@ -583,6 +587,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
 template <int NT, int WC, int WP, int FC, int FP, int MODE, int PIPE = 0, int MF = 0>
 static int launch_conv(ConvArgs &a, hipStream_t s) {
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
+    g_last_kernel = MODE == 1 ? MD_CONV_KERNEL_IGEMM_GENERIC_K : (CT == 128 && PT == 128 && PIPE == 0 ? MD_CONV_KERNEL_IGEMM_128 :
+                    (CT < 128 ? MD_CONV_KERNEL_IGEMM_SMALL_COUT : MD_CONV_KERNEL_OTHER));
     a.n_ctiles = (a.Cout + CT - 1) / CT;
     a.n_ptiles = (a.M + PT - 1) / PT;
     // one staging buffer is enough when the whole K fits one tile (1x1 convs on 64 channels): more
@@ -992,6 +998,7 @@ static int launch_conv_ring32(ConvArgs &a, hipStream_t s) {
 
 
 static int launch_conv3x3_halo(ConvArgs &a, hipStream_t s) {
+    g_last_kernel = MD_CONV_KERNEL_HALO;
     const int tiles_x = (a.W + HT_W - 1) / HT_W, tiles_y = (a.H + HT_H - 1) / HT_H;
     a.n_ctiles = (a.Cout + 127) / 128;
     a.n_ptiles = a.N * tiles_x * tiles_y;
@@ -1351,6 +1358,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 
 template <int ABL = 0, int MF = 0>
 static int launch_conv_pingpong(ConvArgs &a, hipStream_t s) {
+    g_last_kernel = MD_CONV_KERNEL_PINGPONG;
     a.n_ctiles = a.Cout / 256;
     a.n_ptiles = (a.M + 255) / 256;
     a.pt_per_xcd = (a.n_ptiles + 7) / 8;
@@ -1369,6 +1377,8 @@ using namespace md;
 
 // Required weight padding for a given Cout (the tile the dispatcher will pick): exported so the
 // host packer pads consistently.
+extern "C" int md_conv2d_last_kernel(void) { return g_last_kernel; }
+
 extern "C" int md_conv2d_cout_tile(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 
 extern "C" int md_conv2d(MD_AOT_ARGS) {

@@ -400,11 +400,41 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(const float *__restri
     __syncthreads();
     const unsigned b1 = (unsigned)s_b1;  // stays 0 when fewer than k scores are selectable: everything is a candidate
     const unsigned omin = ford(min_score);
-    for (int i = c0 + tid; i < c1; i += 256) {
-        const unsigned u = ford(scores[beg + i]);
-        if (u > omin && (u >> 21) >= b1) {
-            const unsigned pos = atomicAdd(&cand_cnt[seg], 1u);
-            if (pos < (unsigned)TK_CAP) cand[(size_t)seg * TK_CAP + pos] = ((unsigned long long)(~u) << 32) | (unsigned)i;
+    // The chunk's 32 elements per thread stay in registers; ONE atomicAdd per workgroup reserves its slice of the
+    // candidate list (r01: one same-address atomic per candidate serialised in L2 and made this kernel 10x the
+    // histogram pass).  Candidate order is irrelevant: topk_final_kernel sorts by (score, index).
+    constexpr int PER = TK_CHUNK / 256;
+    unsigned u[PER];
+    unsigned cnt = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = c0 + tid + 256 * j;
+        u[j] = i < c1 ? ford(scores[beg + i]) : 0u;
+        if (i >= c1 || !(u[j] > omin && (u[j] >> 21) >= b1)) u[j] = 0u;  // ford() of a selectable score is never 0
+        cnt += u[j] != 0u;
+    }
+    unsigned inc = cnt;  // inclusive prefix over the wave, then wave bases through LDS
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();  // part[] is reused
+    if (lane == 63) part[wv] = inc;
+    __syncthreads();
+    unsigned wbase = 0, total = 0;
+    for (int w = 0; w < 4; ++w) {
+        if (w < wv) wbase += part[w];
+        total += part[w];
+    }
+    if (tid == 0) part[8] = total ? atomicAdd(&cand_cnt[seg], total) : 0u;
+    __syncthreads();
+    unsigned pos = part[8] + wbase + inc - cnt;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        if (u[j] != 0u) {
+            if (pos < (unsigned)TK_CAP) cand[(size_t)seg * TK_CAP + pos] = ((unsigned long long)(~u[j]) << 32) | (unsigned)(c0 + tid + 256 * j);
+            ++pos;
         }
     }
 }

@@ -21,14 +21,21 @@ def per_kernel(d):
 fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
 steps = int(sys.argv[3])
 batch = int(sys.argv[4])
-conv = [k for k in fetch if "conv_igemm_kernel" in k or "conv3x3_halo_kernel" in k or "conv_ring32_kernel" in k]
+conv = [k for k in fetch if "conv_igemm_kernel" in k or "conv3x3_halo_kernel" in k or "conv_ring32_kernel" in k or "conv_pingpong_kernel" in k]
 f_kb = sum(fetch[k][0] for k in conv)
 w_kb = sum(write[k][0] for k in conv)
 n = sum(fetch[k][1] for k in conv)
-out = {"kernel": "conv_igemm_kernel + conv3x3_halo_kernel (all conv/FC launches)", "profiled_steps": steps,
+out = {"kernel": "conv_pingpong_kernel + conv_igemm_kernel (all conv/FC launches)", "profiled_steps": steps,
        "batch_per_gpu": batch, "launches": n,
        "FETCH_SIZE_KB_raw": f_kb, "WRITE_SIZE_KB": w_kb, "fetch_correction": 2.0,
        "hbm_bytes_per_step": (2.0 * f_kb + w_kb) * 1024 / steps,
        "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024 / n}
+by = {}
+for k in conv:
+    name = k.split("(")[0].replace("void md::", "").split("<")[0]
+    d = by.setdefault(name, [0.0, 0.0, 0])
+    d[0] += fetch[k][0]; d[1] += write[k][0]; d[2] += fetch[k][1]
+out["by_kernel"] = {n_: {"launches": d[2], "FETCH_SIZE_KB_raw": d[0], "WRITE_SIZE_KB": d[1],
+                         "hbm_bytes_per_launch": (2.0 * d[0] + d[1]) * 1024 / d[2]} for n_, d in by.items()}
 json.dump(out, open(sys.argv[5], "w"), indent=1)
 print(out)
