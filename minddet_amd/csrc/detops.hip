@@ -566,6 +566,87 @@ __global__ void roi_align_kernel(RoiArgs a, const float *__restrict__ rois, int 
     }
 }
 
+// 32 channels per thread (C % 32 == 0): the RoI / bin / tap arithmetic is paid once per 64 B instead of once per 16 B, and
+// the accumulation runs on channel PAIRS (v_pk_fma_f32).  Same sampling arithmetic as roi_align_kernel; the 16 tap terms of
+// a bin are fused-multiply-added one by one (different fp32 rounding than the 4-term sums there, same bf16 tolerance).  r01: the 16-B kernel was VALU-bound.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void roi_align_c32_kernel(RoiArgs a, const float *__restrict__ rois, int R, uint16_t *__restrict__ out,
+                                                            int *__restrict__ out_level) {
+    const int cv = a.C / 32;
+    const size_t total = (size_t)R * a.P * a.P * cv;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c32 = (int)(e % cv);
+        size_t t = e / cv;
+        const int pw = (int)(t % a.P); t /= a.P;
+        const int ph = (int)(t % a.P);
+        const int r = (int)(t / a.P);
+        const float *roi = rois + (size_t)r * 5;
+        const int b = (int)roi[0];
+        int lvl = 0;
+        if (a.L > 1) {
+            const float w = roi[3] - roi[1], h = roi[4] - roi[2];
+            const float s = sqrtf(fmaxf(w * h, 0.f));
+            const float lf = floorf((float)a.canonical_level + log2f(s / a.canonical_scale + 1e-6f));
+            lvl = (int)fminf(fmaxf(lf, (float)a.k_min), (float)(a.k_min + a.L - 1)) - a.k_min;
+        }
+        if (out_level && c32 == 0 && ph == 0 && pw == 0) out_level[r] = lvl + a.k_min;
+        const RoiLevel L = a.lv[lvl];
+        const float off = a.aligned ? 0.5f : 0.f;
+        const float x1 = roi[1] * L.scale - off, y1 = roi[2] * L.scale - off;
+        const float x2 = roi[3] * L.scale - off, y2 = roi[4] * L.scale - off;
+        float rw = x2 - x1, rh = y2 - y1;
+        if (!a.aligned) { rw = fmaxf(rw, 1.f); rh = fmaxf(rh, 1.f); }
+        const float bw = rw / (float)a.P, bh = rh / (float)a.P;
+        const int g = a.sampling;
+        f32x2 acc[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = (f32x2){0.f, 0.f};
+        const uint16_t *base = L.feat + (size_t)b * L.H * L.W * a.C + c32 * 32;
+        for (int iy = 0; iy < g; ++iy) {
+            const float y = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)g;
+            for (int ix = 0; ix < g; ++ix) {
+                const float x = x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)g;
+                if (y < -1.0f || y > (float)L.H || x < -1.0f || x > (float)L.W) continue;
+                float yy = fmaxf(y, 0.f), xx = fmaxf(x, 0.f);
+                int y_lo = (int)yy, x_lo = (int)xx, y_hi, x_hi;
+                if (y_lo >= L.H - 1) { y_hi = y_lo = L.H - 1; yy = (float)y_lo; } else y_hi = y_lo + 1;
+                if (x_lo >= L.W - 1) { x_hi = x_lo = L.W - 1; xx = (float)x_lo; } else x_hi = x_lo + 1;
+                const float ly = yy - (float)y_lo, lx = xx - (float)x_lo, hy = 1.f - ly, hx = 1.f - lx;
+                const float wt[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
+                const uint16_t *ptr[4] = {base + ((size_t)y_lo * L.W + x_lo) * a.C, base + ((size_t)y_lo * L.W + x_hi) * a.C,
+                                          base + ((size_t)y_hi * L.W + x_lo) * a.C, base + ((size_t)y_hi * L.W + x_hi) * a.C};
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp) {
+                    uint4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const uint4 *>(ptr[tp])[q];
+                    const f32x2 w2 = (f32x2){wt[tp], wt[tp]};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned wd[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const f32x2 pr = (f32x2){__uint_as_float(wd[d] << 16), __uint_as_float(wd[d] & 0xffff0000u)};
+                            acc[q * 4 + d] = __builtin_elementwise_fma(w2, pr, acc[q * 4 + d]);
+                        }
+                    }
+                }
+            }
+        }
+        const float inv = 1.f / (float)(g * g);
+        uint4 *dst = reinterpret_cast<uint4 *>(out + e * 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 o;
+            o.x = rf2bf(acc[q * 4 + 0].x * inv) | (rf2bf(acc[q * 4 + 0].y * inv) << 16);
+            o.y = rf2bf(acc[q * 4 + 1].x * inv) | (rf2bf(acc[q * 4 + 1].y * inv) << 16);
+            o.z = rf2bf(acc[q * 4 + 2].x * inv) | (rf2bf(acc[q * 4 + 2].y * inv) << 16);
+            o.w = rf2bf(acc[q * 4 + 3].x * inv) | (rf2bf(acc[q * 4 + 3].y * inv) << 16);
+            dst[q] = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ CenterNet decode
 // heat [B,C,H,W] f32 (already sigmoid+clip).  keep = (heat == maxpool3x3_same(heat)); out = heat*keep.
 __global__ void heat_nms_kernel(const float *__restrict__ heat, float *__restrict__ out, int H, int W, size_t planes) {
@@ -927,8 +1008,12 @@ extern "C" int md_roi_align(MD_AOT_ARGS) {
     if (numel(ndims, shapes, 1 + L) != R * a.P * a.P * a.C) return MD_ERR_ARG;
     if (R == 0) return MD_OK;
     const size_t total = (size_t)R * a.P * a.P * (a.C / 8);
-    hipLaunchKernelGGL(roi_align_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, a,
-                       (const float *)params[0], (int)R, (uint16_t *)params[1 + L], (int *)params[2 + L]);
+    if (a.C % 32 == 0)
+        hipLaunchKernelGGL(roi_align_c32_kernel, dim3(grid1d(total / 4)), dim3(256), 0, (hipStream_t)stream, a,
+                           (const float *)params[0], (int)R, (uint16_t *)params[1 + L], (int *)params[2 + L]);
+    else
+        hipLaunchKernelGGL(roi_align_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, a,
+                           (const float *)params[0], (int)R, (uint16_t *)params[1 + L], (int *)params[2 + L]);
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }
