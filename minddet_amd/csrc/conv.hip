@@ -1455,11 +1455,14 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
                          a.Cin % 64 == 0 && ctile == 128;
     // MFMA-bound layers (K >= 1024, Cout a multiple of 256): the 256x256 ping-pong kernel (measured r01, tools/conv_ab.py:
     // +17 % over the halo kernel on 3x3 256->256, +75 % on the 12544->1024 FC; loses on the HBM-bound K < 1024 layers)
-    // and it needs enough 256x256 tiles to occupy the chip: one workgroup per CU, so compare whole rounds of 256
-    // ping-pong tiles (at ~1.2x the per-CU rate) with rounds of 1024 resident 128x128 tiles
+    // and it needs enough 256x256 tiles to fill whole rounds of the 256 CUs (one workgroup per CU, ~1.2x the per-CU rate
+    // of four resident 128x128 workgroups; a partial last round costs a full tile time, while the 128x128 kernel's
+    // stragglers run alone on their CUs and finish faster).  Unit: one 128x128 tile at the full-CU 128x128 rate.
     const long long pp_blocks = (M + 255) / 256 * (a.Cout / 256), sb_blocks = (M + 127) / 128 * ((a.Cout + 127) / 128);
-    const bool pp_ok = fast && dma_ok && a.Cout % 256 == 0 && a.Kpad >= 1024 && pp_blocks >= 128 &&
-                       (pp_blocks + 255) / 256 * 10 <= (sb_blocks + 1023) / 1024 * 12;
+    const double t_pp = (double)((pp_blocks + 255) / 256) * (4.0 / 1.2);
+    const double sb_last = (double)(sb_blocks % 1024) / 1024.0;
+    const double t_sb = (double)(sb_blocks / 1024) * 4.0 + (sb_blocks % 1024 ? 1.5 + 2.5 * sb_last : 0.0);
+    const bool pp_ok = fast && dma_ok && a.Cout % 256 == 0 && a.Kpad >= 1024 && pp_blocks >= 128 && t_pp <= t_sb;
     if (variant == 0 && pp_ok) return launch_conv_pingpong<0>(a, s);
     if (halo_ok && !a.res_up && variant == 11) return launch_conv3x3_halo(a, s);  // superseded by the two paths around it
     if (variant == 11) variant = 2;
