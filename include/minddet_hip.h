@@ -183,6 +183,15 @@ typedef struct md_pool_attrs {
 } md_pool_attrs;
 /* in x[N,H,W,C] bf16 ; out y[N,Ho,Wo,C] bf16.  extra: md_pool_attrs (required). */
 int md_maxpool2d(MD_AOT_ARGS);
+/* The ResNet stem in one launch: conv 7x7 / s2 / p3 (3 -> 64) + folded BN + ReLU + zero-pad + MaxPool 3x3 / s2
+ * (minddet/models/centernet/src/resnet.py:199-204 and :226-233; the stem of every ResNet graph of the reference).
+ * in : x[N, H+16, W+16, 4] bf16 -- the image in the STEM LAYOUT: channels (c0, c1, c2, 0), a zero border of
+ *      md_stem_layout_pad(0) = 7 pixels on the left / top and md_stem_layout_pad(1) = 9 on the right / bottom;
+ *      w[64, 224] bf16 -- BN-folded weights, K = (ky 0..6, kx 0..7, c 0..3) with kx 7 and c 3 zero; bias[64] f32
+ * out: y[N, H/4, W/4, 64] bf16.   H % 16 == 0 and W % 64 == 0 (else MD_ERR_ARG: use md_conv2d + md_maxpool2d). */
+int md_stem_pool(MD_AOT_ARGS);
+int md_stem_layout_pad(int which);
+
 /* FPN top-down step: in lateral[N,H,W,C], top[N,Ht,Wt,C] bf16 ; out y = lateral + nearest_up(top). */
 int md_upsample_add(MD_AOT_ARGS);
 typedef struct md_slice_attrs {

@@ -138,11 +138,21 @@ class ResNet:
     def to(self, device):
         for m in self.modules():
             m.to(device)
+        self.stem = None
+        if self.conv1.cout == 64 and self.conv1.relu:  # the fused conv + BN + ReLU + maxpool kernel (md_stem_pool)
+            self.stem = nn_ops.pack_stem(self.conv1.weight, bn=self.conv1.bn, bias=self.conv1.bias).to(device)
         return self
 
     def __call__(self, x):
-        x = self.conv1(x)
-        x = nn_ops.maxpool2d(x, 3, 2, 1, zero_pad=True)
+        """x: [N,H,W,8] bf16 NHWC (3 real channels), or the same batch already in the stem layout
+        ([N,H+16,W+16,4], nn_ops.to_stem_layout) -- then the whole stem is one launch."""
+        if x.shape[3] == 4:
+            if self.stem is None:
+                raise nn_ops._lib.MindDetHipError("ResNet: stem-layout input needs the 64-channel ReLU stem")
+            x = nn_ops.stem_pool(x, self.stem)
+        else:
+            x = self.conv1(x)
+            x = nn_ops.maxpool2d(x, 3, 2, 1, zero_pad=True)
         outs = []
         for st in self.stages:
             for b in st:
@@ -342,6 +352,8 @@ class FasterRCNN:
 
     def forward(self, images, return_aux=False):
         img_hw = (images.shape[1], images.shape[2])
+        if images.shape[3] == 4:  # stem layout (nn_ops.to_stem_layout): the border is not image
+            img_hw = (img_hw[0] - nn_ops.STEM_PAD_LO - nn_ops.STEM_PAD_HI, img_hw[1] - nn_ops.STEM_PAD_LO - nn_ops.STEM_PAD_HI)
         feats = self.extract_feat(images)
         rois, roi_scores, roi_cnt, aux_rpn = self.rpn_head(feats, img_hw)
         dets, count, aux_roi = self.roi_head(feats, rois, roi_cnt, img_hw)

@@ -227,3 +227,57 @@ def upsample2x(src, dst=None, c0=0):
         dst = torch.empty((n, 2 * h, 2 * w, c), dtype=torch.bfloat16, device=src.device)
     _lib.call("md_upsample2x", [src, dst], extra=_SliceAttrs(int(c0), c))
     return dst
+
+
+# ----------------------------------------------------------------------------- fused ResNet stem (csrc/stem.hip)
+STEM_PAD_LO, STEM_PAD_HI = 7, 9
+
+
+class PackedStem:
+    def __init__(self, w, bias):
+        self.w, self.bias = w, bias
+
+    def to(self, device):
+        self.w, self.bias = self.w.to(device), self.bias.to(device)
+        return self
+
+
+def pack_stem(weight, bn=None, bias=None):
+    """weight [64,3,7,7] fp32 (+ eval BatchNorm) -> md_stem_pool operands: w [64, 224] bf16 with K = (ky, kx 0..7, c 0..3)."""
+    weight = weight.detach().to(torch.float32)
+    cout, cin, kh, kw = weight.shape
+    if (cout, kh, kw) != (64, 7, 7) or cin > 3:
+        raise _lib.MindDetHipError("pack_stem: expects a [64, <=3, 7, 7] stem convolution")
+    if bn is not None:
+        gamma, beta, mean, var, eps = bn
+        scale = gamma.to(torch.float32) / torch.sqrt(var.to(torch.float32) + eps)
+        weight = weight * scale.view(-1, 1, 1, 1)
+        b = beta.to(torch.float32) - mean.to(torch.float32) * scale
+        if bias is not None:
+            b = b + bias.to(torch.float32) * scale
+    else:
+        b = bias.detach().to(torch.float32) if bias is not None else torch.zeros(cout)
+    wp = torch.zeros((64, 7, 8, 4), dtype=torch.float32)
+    wp[:, :, :7, :cin] = weight.permute(0, 2, 3, 1)
+    return PackedStem(wp.reshape(64, 224).to(torch.bfloat16).contiguous(), b.contiguous())
+
+
+def stem_layout_ok(h, w):
+    return h % 16 == 0 and w % 64 == 0
+
+
+def to_stem_layout(x):
+    """[N,H,W,>=3] bf16 NHWC image batch -> [N, H+16, W+16, 4] (the input layout of md_stem_pool).  Layout plumbing for
+    callers that hold the 8-channel format; a pre-processing pipeline writes this layout directly."""
+    n, h, w, _ = x.shape
+    out = torch.zeros((n, h + STEM_PAD_LO + STEM_PAD_HI, w + STEM_PAD_LO + STEM_PAD_HI, 4), dtype=torch.bfloat16, device=x.device)
+    out[:, STEM_PAD_LO:STEM_PAD_LO + h, STEM_PAD_LO:STEM_PAD_LO + w, :3] = x[..., :3]
+    return out
+
+
+def stem_pool(x4, ps):
+    n, hp, wp, c = x4.shape
+    h, w = hp - STEM_PAD_LO - STEM_PAD_HI, wp - STEM_PAD_LO - STEM_PAD_HI
+    y = torch.empty((n, h // 4, w // 4, 64), dtype=torch.bfloat16, device=x4.device)
+    _lib.call("md_stem_pool", [x4, ps.w, ps.bias, y])
+    return y

@@ -134,3 +134,35 @@ def test_conv_fused_upsampled_residual():
         up = top.float().repeat_interleave(2, 1).repeat_interleave(2, 2)[:, :h, :w]
         ref = c.to(torch.bfloat16).float() + up
         assert ((y - ref).abs() <= 1.5e-2 * ref.abs() + 1.5e-2).all()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 128), (1, 32, 64), (3, 48, 192)])
+def test_stem_pool_vs_torch_fp32(shape):
+    """md_stem_pool (conv 7x7/2 + BN + ReLU + zero-pad + maxpool 3x3/2 in one launch) vs fp32 torch on the same
+    bf16-rounded operands, and vs the two-launch path (md_conv2d + md_maxpool2d).  Tolerance as above (bf16 output)."""
+    from minddet_amd import nn_ops
+
+    n, h, w = shape
+    g = torch.Generator().manual_seed(11 + h)
+    x = torch.randn((n, h, w, 3), generator=g)
+    wt = torch.randn((64, 3, 7, 7), generator=g) * (2.0 / 147) ** 0.5
+    bn = (torch.rand((64,), generator=g) + 0.5, torch.randn((64,), generator=g) * 0.1,
+          torch.randn((64,), generator=g) * 0.1, torch.rand((64,), generator=g) + 0.5, 1e-5)
+    x8 = torch.zeros((n, h, w, 8))
+    x8[..., :3] = x
+    xb = x8.to(torch.bfloat16).to(DEV)
+    ps = nn_ops.pack_stem(wt, bn=bn).to(DEV)
+    y = nn_ops.stem_pool(nn_ops.to_stem_layout(xb), ps).float().cpu()
+    # fp32 reference on the bf16-rounded packed operands
+    wf = ps.w.float().cpu().reshape(64, 7, 8, 4)[:, :, :7, :3].permute(0, 3, 1, 2)
+    c = F.conv2d(xb.float().cpu()[..., :3].permute(0, 3, 1, 2), wf, ps.bias.cpu(), stride=2, padding=3)
+    c = torch.relu(c).to(torch.bfloat16).float()
+    ref = F.max_pool2d(F.pad(c, (1, 1, 1, 1)), 3, 2).permute(0, 2, 3, 1)
+    assert y.shape == ref.shape == (n, h // 4, w // 4, 64)
+    rms = ref.pow(2).mean().sqrt().item()
+    assert ((y - ref).abs() <= 1.2e-2 * ref.abs() + 1.2e-2 * rms).all()
+    # the generic two-launch path computes the same function
+    pc = nn_ops.pack_conv(wt, bn=bn, stride=2, pad=3, relu=True).to(DEV)
+    y2 = nn_ops.maxpool2d(nn_ops.conv2d(xb, pc), 3, 2, 1, zero_pad=True).float().cpu()
+    assert ((y - y2).abs() <= 1.2e-2 * ref.abs() + 1.2e-2 * rms).all()
+    assert (y == y2).float().mean() > 0.98

@@ -43,6 +43,26 @@ def test_backbone_fpn_features_vs_torch_fp32(tiny):
         assert err <= 3e-2 * max(rms, 1e-3) + 3e-2 * f_ref.abs().max().item() * 0.1, (err, rms)
 
 
+def test_stem_layout_path_matches_oracle(tiny):
+    """The same batch handed over in the stem layout (one md_stem_pool launch instead of conv + maxpool) gives
+    the same pyramid within the conv tolerance, and the detector runs end to end on it."""
+    from minddet_amd import nn_ops
+
+    m, xb, dets, count, aux = tiny
+    x4 = nn_ops.to_stem_layout(xb.to(DEV))
+    assert x4.shape == (2, 128 + 16, 192 + 16, 4)
+    x = xb[..., :3].float().permute(0, 3, 1, 2).contiguous()
+    ref = nets.fpn_forward(m.neck, nets.resnet_forward(m.backbone, x, quant=True), quant=True)
+    for f_dev, f_ref in zip(m.extract_feat(x4), ref):
+        got = f_dev.float().cpu().permute(0, 3, 1, 2)
+        rms = f_ref.pow(2).mean().sqrt().item()
+        err = (got - f_ref).abs().max().item()
+        assert err <= 3e-2 * max(rms, 1e-3) + 3e-2 * f_ref.abs().max().item() * 0.1, (err, rms)
+    d4, c4 = m.forward(x4)
+    assert d4.shape == dets.shape and c4.shape == count.shape
+    assert (c4.cpu() - count.cpu()).abs().max().item() <= 3  # a last-bit score difference may move a detection over a threshold
+
+
 def test_rpn_stage_indices_exact(tiny):
     m, xb, _, _, aux = tiny
     rpn = m.rpn_head
