@@ -131,21 +131,28 @@ def main():
             d[0] += t_ms; d[1] += r[2]; d[2] += r[6]; d[3] += 1
         dom = max(per_k, key=lambda k_: per_k[k_][0])
         d_ms, d_fl, d_by, d_n = per_k[dom]
-        ach = d_fl / (d_ms * 1e-3) / 1e12
+        # which roofline binds the dominant kernel's launches in aggregate: HBM (algorithmic bytes / 8 TB/s) or MFMA
+        # (algorithmic flops / 2.5 PFLOP/s dense bf16)
+        hbm_bound = d_by / PEAK_HBM_BPS > d_fl / (PEAK_BF16_TFLOPS * 1e12)
+        ach = d_by / (d_ms * 1e-3) / 1e9 if hbm_bound else d_fl / (d_ms * 1e-3) / 1e12
+        peak = PEAK_HBM_BPS / 1e9 if hbm_bound else PEAK_BF16_TFLOPS
         # layer-wise roofline: each launch is bounded by max(flops / MFMA peak, algorithmic bytes / HBM peak)
         t_roof_ms = sum(max(r[2] / (PEAK_BF16_TFLOPS * 1e12), r[6] / PEAK_HBM_BPS) for r in records) * 1e3
         traffic = all_traffic = None
         tp = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+        PMC_NAMES = {1: "conv_pingpong_kernel<0, 0>", 2: "conv_igemm_kernel<256, 2, 2, 2, 2, 2, 0, 0>"}
         if os.path.exists(tp):  # PMC passes are separate rocprofv3 runs (tools/pmc_traffic.py); same config only
             tj = json.load(open(tp))
             if tj.get("batch_per_gpu") == B and type(model).__name__ == "FasterRCNN":
                 all_traffic = round(tj["hbm_bytes_per_launch"] / 1e6, 2)
-                bk = tj.get("by_kernel", {}).get(KNAMES.get(dom, "").split("<")[0])
-                if bk and dom == 1:
+                bk = tj.get("by_kernel", {}).get(PMC_NAMES.get(dom, ""))
+                if bk:
                     traffic = round(bk["hbm_bytes_per_launch"] / 1e6, 2)
-        roofline = {"bound": "mfma", "kernel": KNAMES.get(dom, str(dom)) + " (dominant kernel: %.0f %% of the conv/FC time)" % (100 * d_ms / tot_ms),
-                    "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+        roofline = {"bound": "hbm" if hbm_bound else "mfma",
+                    "kernel": KNAMES.get(dom, str(dom)) + " (dominant kernel: %.0f %% of the conv/FC time)" % (100 * d_ms / tot_ms),
+                    "achieved": round(ach, 2), "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_unit": "MB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_conv_traffic.json)",
+                    "achieved_tflops": round(d_fl / (d_ms * 1e-3) / 1e12, 2),
                     "algorithmic_mb_per_launch": round(d_by / d_n / 1e6, 2),
                     "algorithmic_gflop_per_launch": round(d_fl / d_n / 1e9, 1),
                     "launches_per_step": d_n // max(args.steps, 1),

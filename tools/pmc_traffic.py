@@ -32,7 +32,7 @@ out = {"kernel": "conv_pingpong_kernel + conv_igemm_kernel (all conv/FC launches
        "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024 / n}
 by = {}
 for k in conv:
-    name = k.split("(")[0].replace("void md::", "").split("<")[0]
+    name = k.split("(")[0].replace("void md::", "").strip()  # keeps the template arguments: one entry per instantiation
     d = by.setdefault(name, [0.0, 0.0, 0])
     d[0] += fetch[k][0]; d[1] += write[k][0]; d[2] += fetch[k][1]
 out["by_kernel"] = {n_: {"launches": d[2], "FETCH_SIZE_KB_raw": d[0], "WRITE_SIZE_KB": d[1],
