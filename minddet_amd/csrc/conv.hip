@@ -54,6 +54,8 @@ struct ConvArgs {
     int adv;                // 0: plain (off = m*Cout + c)
     int korder;             // 0: K = (tap, ci); 1: K = (ci/64, tap, ci%64)  (MODE 2 only)
     int single_buf;         // PIPE 0 LDS-DMA loop with ONE staging buffer (short-K layers: more workgroups per CU)
+    int bias_lds_off;       // byte offset of the CT-float bias copy in LDS (past the staging buffers and the epilogue image)
+    int stamp;              // diagnostic (variant 25): a mid-grid workgroup overwrites the first output bytes with s_memtime stamps
     int res_up;             // 1: residual is [N, ceil(Ho/2), ceil(Wo/2), Cout], read with nearest 2x upsampling
                             //    (the FPN top-down add fused into the lateral 1x1 conv); plain addressing only
 };
@@ -131,6 +133,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
     const int ct = slot % a.n_ctiles, pt = xcd * a.pt_per_xcd + slot / a.n_ctiles;
     if (pt >= a.n_ptiles) return;
     const int cout0 = ct * CT, pix0 = pt * PT;
+    unsigned long long stp[6] = {0, 0, 0, 0, 0, 0};
+    if (a.stamp) stp[0] = __builtin_readcyclecounter();
+    // The tile's bias is requested NOW and parked in LDS for the epilogue.  r01 stamps (tools/igemm_stamps.py): fetched
+    // after the K loop, this one dependent global load exposed 9-12k cycles of loaded-HBM latency in every workgroup.
+    const float bias_early = tid < CT ? a.bias[cout0 + tid] : 0.f;
 
     // this thread stages rows row0 + RPP*i; physical 16-B slot (tid & 7) of the row holds LOGICAL k-chunk
     // `chunk` (the swizzle term (row>>1)&7 is the same for all of a thread's rows because RPP % 16 == 0)
@@ -458,9 +465,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
                 dma_tile(kt, 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                if (a.stamp && kt == 0) stp[1] = __builtin_readcyclecounter();
                 compute_tile(0);
                 __syncthreads();
             }
+            if (a.stamp) stp[2] = __builtin_readcyclecounter();
         } else {
         dma_tile(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
@@ -514,13 +523,16 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
     }
     // bias (+ReLU when no residual) -> bf16x4 -> LDS [pixel][cout] image
     char *E = smem;
+    float *bias_lds = reinterpret_cast<float *>(smem + a.bias_lds_off);
+    if (tid < CT) bias_lds[tid] = bias_early;
+    __syncthreads();
     if (is_loader) {
         // staging waves hold no accumulators
     } else if constexpr (MF == 1) {
 #pragma unroll
         for (int i = 0; i < 2 * FC; ++i) {
             const int c_local = (wc * FC * 2 + i) * 16 + 4 * lq;  // 4 consecutive couts
-            const float4 bv = *reinterpret_cast<const float4 *>(a.bias + cout0 + c_local);
+            const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + c_local);
 #pragma unroll
             for (int j = 0; j < 2 * FP; ++j) {
                 const int p_local = (wp * FP * 2 + j) * 16 + l16;
@@ -542,7 +554,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c_local = (wc * FC + i) * 32 + 8 * g + 4 * lh;  // 4 consecutive couts
-            const float4 bv = *reinterpret_cast<const float4 *>(a.bias + cout0 + c_local);
+            const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + c_local);
 #pragma unroll
             for (int j = 0; j < FP; ++j) {
                 const int p_local = (wp * FP + j) * 32 + lr;
@@ -560,7 +572,9 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
             }
         }
     }
+    if (a.stamp) stp[3] = __builtin_readcyclecounter();
     __syncthreads();
+    if (a.stamp) stp[4] = __builtin_readcyclecounter();
     // ---- coalesced NHWC store: 16 B (8 couts) per lane, CT/8 lanes per pixel
 #pragma unroll
     for (int it = 0; it < EP_ITERS; ++it) {
@@ -582,6 +596,16 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         }
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + off));
     }
+    if (a.stamp && blockIdx.x == gridDim.x / 2) {
+        stp[5] = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_done = __builtin_readcyclecounter();
+        if (tid == 0) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(a.y);
+            for (int i = 0; i < 6; ++i) dbg[i] = stp[i];
+            dbg[6] = t_done;
+        }
+    }
 }
 
 template <int NT, int WC, int WP, int FC, int FP, int MODE, int PIPE = 0, int MF = 0>
@@ -597,7 +621,8 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
     const int nbuf = PIPE == 2 ? 4 : (PIPE == 1 ? 3 : (a.Kpad / BK > 1 && !a.single_buf ? 2 : 1));
     const int tile_bytes = (CT + PT) * ROWB * nbuf;
     constexpr int ep_bytes = PT * (CT * 2 + 16);
-    const int lds = tile_bytes > ep_bytes ? tile_bytes : ep_bytes;
+    a.bias_lds_off = tile_bytes > ep_bytes ? tile_bytes : ep_bytes;
+    const int lds = a.bias_lds_off + CT * 4;
     a.pt_per_xcd = (a.n_ptiles + 7) / 8;
     const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
@@ -1055,6 +1080,9 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     if (pt >= a.n_ptiles) return;
     const int cout0 = ct * CT, pix0 = pt * PT;
     const int n_taps = a.kh * a.kw, nk = a.Kpad / BK;
+    // bias: requested now, parked in LDS past the epilogue image after the prologue wait (see conv_igemm_kernel)
+    const float bias_early = tid < CT ? a.bias[cout0 + tid] : 0.f;
+    float *bias_lds = reinterpret_cast<float *>(smem + PT * EP_STRIDE);
 
     __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
@@ -1201,7 +1229,8 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     walk_next(w2);
     stage_A(0, 0, H_A0); stage_B(0, 0, H_B0, w0); stage_B(0, 1, H_B1, w0); stage_A(0, 1, H_A1);
     stage_A(1, 0, H_A0); stage_B(1, 0, H_B0, w1); stage_B(1, 1, H_B1, w1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // also retires the (older) bias load
+    if (tid < CT) bias_lds[tid] = bias_early;         // read in the epilogue, hundreds of barriers later
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs half a phase behind group 0
     __builtin_amdgcn_sched_barrier(0);
@@ -1262,7 +1291,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c_local = wr * 128 + i * 16 + 4 * lq;  // 4 consecutive couts
-            const float4 bv = *reinterpret_cast<const float4 *>(a.bias + cout0 + c_local);
+            const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + c_local);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int p_local = wc * 64 + j * 16 + l16;
@@ -1284,7 +1313,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c_local = wr * 128 + i * 32 + 8 * g + 4 * lh;
-            const float4 bv = *reinterpret_cast<const float4 *>(a.bias + cout0 + c_local);
+            const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + c_local);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int p_local = wc * 64 + j * 32 + lr;
@@ -1364,7 +1393,7 @@ static int launch_conv_pingpong(ConvArgs &a, hipStream_t s) {
     a.pt_per_xcd = (a.n_ptiles + 7) / 8;
     const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
-    const int lds = 256 * (256 * 2 + 16);  // 135,168 B: the epilogue image (>= the 128 KiB of staging buffers)
+    const int lds = 256 * (256 * 2 + 16) + 256 * 4;  // 136,192 B: the epilogue image (>= the 128 KiB of staging buffers) + bias
     if (hipFuncSetAttribute((const void *)conv_pingpong_kernel<ABL, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MD_ERR_HIP;
     hipLaunchKernelGGL((conv_pingpong_kernel<ABL, MF>), dim3((unsigned)blocks), dim3(512), lds, s, a);
@@ -1405,7 +1434,9 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     a.res_up = at->res_upsample != 0 && params[3] != nullptr;
     // one LDS staging buffer by default: measured r01 (tools/conv_ab.py), 4 resident workgroups per CU with a serial
     // DMA -> MFMA loop beat 2 double-buffered ones on every benchmark layer (+8...43 %); variant 2 keeps the double buffer
-    a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 21;
+    a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 21 || at->variant == 25;
+    a.stamp = at->variant == 25;
+    if (at->variant == 25) variant_override = 2;
     if (at->variant == 20) variant_override = 2;
     if (a.res_up && a.adv) return MD_ERR_ARG;
     if (!a.adv) {
