@@ -11,14 +11,11 @@ from minddet_amd import nn_ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 LAYERS = [  # (H, W, Cin, Cout, k, stride, residual)
     (200, 336, 256, 256, 3, 1, False), (100, 168, 256, 256, 3, 1, False), (50, 84, 256, 256, 3, 1, False),
-    (25, 42, 256, 256, 3, 1, False), (200, 336, 64, 256, 1, 1, True), (200, 336, 64, 64, 3, 1, False),
+    (200, 336, 64, 256, 1, 1, True), (200, 336, 64, 256, 1, 1, False), (200, 336, 64, 64, 3, 1, False),
     (200, 336, 256, 64, 1, 1, False), (100, 168, 128, 512, 1, 1, True), (100, 168, 128, 128, 3, 1, False),
     (50, 84, 256, 1024, 1, 1, True), (50, 84, 1024, 256, 1, 1, False), (25, 42, 512, 512, 3, 1, False),
     (25, 42, 512, 2048, 1, 1, True), (25, 42, 2048, 512, 1, 1, False), (1, 1000 * B // 8, 12544, 1024, 1, 1, False),
-    (1, 1000 * B // 8, 1024, 1024, 1, 1, False), (800, 1344, 3, 64, 7, 2, False),
-    (200, 336, 256, 256, 1, 1, True), (100, 168, 512, 256, 1, 1, True), (100, 168, 512, 128, 1, 1, False),
-    (200, 336, 256, 16, 1, 1, False), (200, 336, 256, 128, 1, 1, False), (200, 336, 128, 128, 3, 2, False),
-    (200, 336, 256, 512, 1, 2, False),
+    (1, 1000 * B // 8, 1024, 1024, 1, 1, False), (200, 336, 256, 256, 1, 1, True), (100, 168, 512, 128, 1, 1, False),
 ]
 dev = "cuda:0"
 g = torch.Generator().manual_seed(0)
@@ -32,7 +29,7 @@ for (H, W, Cin, Cout, k, s, res) in LAYERS:
     ho, wo = nn_ops.conv_out_hw(H, W, pc)
     r = torch.randn((n, ho, wo, pc.cout), generator=g).to(torch.bfloat16).to(dev) if res else None
     fl = 2.0 * n * ho * wo * Cout * Cin * k * k
-    variants = [0, 15, 20] if nn_ops.cout_tile(pc.cout) == 128 else [2, 20]
+    variants = [0, 2, 15] if nn_ops.cout_tile(pc.cout) == 128 else [2, 20]
     outs, times = {}, {v: [] for v in variants}
     def run(v):
         if v >= 100:
