@@ -69,6 +69,14 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
     return (uint16_t)(u >> 16);
 }
 
+// two fp32 -> packed bf16 (round-to-nearest-even) in ONE instruction (gfx950 v_cvt_pk_bf16_f32).  r01 stamps: the software
+// rounding (9 VALU per value, 64 values per lane) made the epilogue VALU-bound at four workgroups per CU.
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
 
 constexpr int BK = 64;
@@ -543,8 +551,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
                     v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
                 }
                 uint2 pk;
-                pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-                pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                pk.x = pk_bf16(v0, v1);
+                pk.y = pk_bf16(v2, v3);
                 *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
             }
         }
@@ -566,8 +574,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
                     v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
                 }
                 uint2 pk;
-                pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-                pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                pk.x = pk_bf16(v0, v1);
+                pk.y = pk_bf16(v2, v3);
                 *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
             }
         }
@@ -591,7 +599,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
                 float lo = bf2f((uint16_t)(v[k] & 0xffff)) + bf2f((uint16_t)(rv[k] & 0xffff));
                 float hi = bf2f((uint16_t)(v[k] >> 16)) + bf2f((uint16_t)(rv[k] >> 16));
                 if (a.relu == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                v[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                v[k] = pk_bf16(lo, hi);
             }
         }
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + off));
@@ -795,8 +803,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a, int ti
                     v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
                 }
                 uint2 pk;
-                pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-                pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                pk.x = pk_bf16(v0, v1);
+                pk.y = pk_bf16(v2, v3);
                 *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
             }
         }
@@ -816,7 +824,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a, int ti
                 float lo = bf2f((uint16_t)(v[k] & 0xffff)) + bf2f((uint16_t)(rv[k] & 0xffff));
                 float hi = bf2f((uint16_t)(v[k] >> 16)) + bf2f((uint16_t)(rv[k] >> 16));
                 if (a.relu == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                v[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                v[k] = pk_bf16(lo, hi);
             }
         }
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + off));
@@ -981,8 +989,8 @@ __global__ __launch_bounds__(256, 3) void conv_ring32_kernel(ConvArgs a) {
                     v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
                 }
                 uint2 pk;
-                pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-                pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                pk.x = pk_bf16(v0, v1);
+                pk.y = pk_bf16(v2, v3);
                 *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
             }
         }
@@ -1003,7 +1011,7 @@ __global__ __launch_bounds__(256, 3) void conv_ring32_kernel(ConvArgs a) {
                 float lo = bf2f((uint16_t)(v[k] & 0xffff)) + bf2f((uint16_t)(rv[k] & 0xffff));
                 float hi = bf2f((uint16_t)(v[k] >> 16)) + bf2f((uint16_t)(rv[k] >> 16));
                 if (a.relu == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                v[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                v[k] = pk_bf16(lo, hi);
             }
         }
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + off));
@@ -1302,8 +1310,8 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
                     v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
                 }
                 uint2 pk;
-                pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-                pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                pk.x = pk_bf16(v0, v1);
+                pk.y = pk_bf16(v2, v3);
                 *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
             }
         }
@@ -1325,8 +1333,8 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
                     v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
                 }
                 uint2 pk;
-                pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-                pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                pk.x = pk_bf16(v0, v1);
+                pk.y = pk_bf16(v2, v3);
                 *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
             }
         }
@@ -1369,7 +1377,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
                 float lo = bf2f((uint16_t)(v[k] & 0xffff)) + bf2f((uint16_t)(rv[k] & 0xffff));
                 float hi = bf2f((uint16_t)(v[k] >> 16)) + bf2f((uint16_t)(rv[k] >> 16));
                 if (a.relu == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                v[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                v[k] = pk_bf16(lo, hi);
             }
         }
         if (ABL == 2 && v[0] != 0x12345u) continue;

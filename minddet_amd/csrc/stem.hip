@@ -63,6 +63,12 @@ __device__ __forceinline__ uint16_t st_f2bf(float f) {
     return (uint16_t)(u >> 16);
 }
 
+__device__ __forceinline__ unsigned st_pk_bf16(float lo, float hi) {  // RNE, one instruction (gfx950)
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
 __device__ __forceinline__ unsigned pk_max_u16(unsigned x, unsigned y) {
     unsigned r;
     asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
@@ -153,8 +159,8 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemArgs a) {
                 float v0 = fmaxf(acc[f][4 * g + 0] + bv[g].x, 0.f), v1 = fmaxf(acc[f][4 * g + 1] + bv[g].y, 0.f);
                 float v2 = fmaxf(acc[f][4 * g + 2] + bv[g].z, 0.f), v3 = fmaxf(acc[f][4 * g + 3] + bv[g].w, 0.f);
                 uint2 pk;
-                pk.x = (unsigned)st_f2bf(v0) | ((unsigned)st_f2bf(v1) << 16);
-                pk.y = (unsigned)st_f2bf(v2) | ((unsigned)st_f2bf(v3) << 16);
+                pk.x = st_pk_bf16(v0, v1);
+                pk.y = st_pk_bf16(v2, v3);
                 if (pad) pk = make_uint2(0u, 0u);
                 *reinterpret_cast<uint2 *>(tile + t_off[f] + (wc * 32 + 8 * g + 4 * lh) * 2) = pk;
             }
