@@ -54,6 +54,7 @@ struct ConvArgs {
     int adv;                // 0: plain (off = m*Cout + c)
     int korder;             // 0: K = (tap, ci); 1: K = (ci/64, tap, ci%64)  (MODE 2 only)
     int single_buf;         // PIPE 0 LDS-DMA loop with ONE staging buffer (short-K layers: more workgroups per CU)
+    int pointwise;          // 1x1 / stride 1 / pad 0 (input pixel index == output pixel index)
     int bias_lds_off;       // byte offset of the CT-float bias copy in LDS (past the staging buffers and the epilogue image)
     int stamp;              // diagnostic (variant 25): a mid-grid workgroup overwrites the first output bytes with s_memtime stamps
     int res_up;             // 1: residual is [N, ceil(Ho/2), ceil(Wo/2), Cout], read with nearest 2x upsampling
@@ -76,6 +77,13 @@ __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
+
+__device__ __forceinline__ unsigned pk_relu_bf16(unsigned v) {  // max(x, 0) on a packed bf16 pair: as signed 16-bit integers
+    unsigned r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(v));
+    return r;
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
 
@@ -162,7 +170,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
     for (int i = 0; i < B_ROWS; ++i) {
         const int m = pix0 + row0 + RPP * i;
         p_hw0[i] = 0; p_base[i] = -1; p_taps[i] = 0u;
-        if (m < a.M) {
+        if (MODE == 2 && a.pointwise) {
+            // 1x1 / stride 1 / pad 0: input pixel == output pixel, no (n, ho, wo) decode (two integer divisions per row:
+            // on the short-K layers this setup cost as many VALU cycles as the whole K loop)
+            if (m < a.M) { p_base[i] = m * a.Cin * 2 + chunk * 16; p_taps[i] = 1u; }
+        } else if (m < a.M) {
             const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
             const int ho = r / a.Wo, wo = r - ho * a.Wo;
             const int hi0 = ho * a.stride - a.pad_top, wi0 = wo * a.stride - a.pad_left;
@@ -566,16 +578,14 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
 #pragma unroll
             for (int j = 0; j < FP; ++j) {
                 const int p_local = (wp * FP + j) * 32 + lr;
-                float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
-                float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
-                if (a.relu == 1 && !a.res) {
-                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                } else if (a.relu == 2) {
-                    v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
-                }
+                // packed adds (v_pk_add_f32), one-instruction bf16 pack, ReLU on the packed pair: 8 VALU per 4 values
+                f32x2 s01 = (f32x2){acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
+                f32x2 s23 = (f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
+                if (a.relu == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
                 uint2 pk;
-                pk.x = pk_bf16(v0, v1);
-                pk.y = pk_bf16(v2, v3);
+                pk.x = pk_bf16(s01.x, s01.y);
+                pk.y = pk_bf16(s23.x, s23.y);
+                if (a.relu == 1 && !a.res) { pk.x = pk_relu_bf16(pk.x); pk.y = pk_relu_bf16(pk.y); }
                 *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
             }
         }
@@ -596,10 +606,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
             const u32x4 rv = rres[it];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float lo = bf2f((uint16_t)(v[k] & 0xffff)) + bf2f((uint16_t)(rv[k] & 0xffff));
-                float hi = bf2f((uint16_t)(v[k] >> 16)) + bf2f((uint16_t)(rv[k] >> 16));
-                if (a.relu == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                v[k] = pk_bf16(lo, hi);
+                const f32x2 sum = (f32x2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)} +
+                                  (f32x2){__uint_as_float(rv[k] << 16), __uint_as_float(rv[k] & 0xffff0000u)};
+                v[k] = pk_bf16(sum.x, sum.y);
+                if (a.relu == 1) v[k] = pk_relu_bf16(v[k]);
             }
         }
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + off));
@@ -795,16 +805,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a, int ti
 #pragma unroll
             for (int j = 0; j < FP; ++j) {
                 const int p_local = (wp * FP + j) * 32 + lr;
-                float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
-                float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
-                if (a.relu == 1 && !a.res) {
-                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                } else if (a.relu == 2) {
-                    v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
-                }
+                // packed adds (v_pk_add_f32), one-instruction bf16 pack, ReLU on the packed pair: 8 VALU per 4 values
+                f32x2 s01 = (f32x2){acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
+                f32x2 s23 = (f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
+                if (a.relu == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
                 uint2 pk;
-                pk.x = pk_bf16(v0, v1);
-                pk.y = pk_bf16(v2, v3);
+                pk.x = pk_bf16(s01.x, s01.y);
+                pk.y = pk_bf16(s23.x, s23.y);
+                if (a.relu == 1 && !a.res) { pk.x = pk_relu_bf16(pk.x); pk.y = pk_relu_bf16(pk.y); }
                 *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
             }
         }
@@ -821,10 +829,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a, int ti
             const u32x4 rv = rres[it];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float lo = bf2f((uint16_t)(v[k] & 0xffff)) + bf2f((uint16_t)(rv[k] & 0xffff));
-                float hi = bf2f((uint16_t)(v[k] >> 16)) + bf2f((uint16_t)(rv[k] >> 16));
-                if (a.relu == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                v[k] = pk_bf16(lo, hi);
+                const f32x2 sum = (f32x2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)} +
+                                  (f32x2){__uint_as_float(rv[k] << 16), __uint_as_float(rv[k] & 0xffff0000u)};
+                v[k] = pk_bf16(sum.x, sum.y);
+                if (a.relu == 1) v[k] = pk_relu_bf16(v[k]);
             }
         }
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + off));
@@ -981,16 +989,14 @@ __global__ __launch_bounds__(256, 3) void conv_ring32_kernel(ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < FP; ++j) {
                 const int p_local = (wp * FP + j) * 32 + lr;
-                float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
-                float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
-                if (a.relu == 1 && !a.res) {
-                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                } else if (a.relu == 2) {
-                    v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
-                }
+                // packed adds (v_pk_add_f32), one-instruction bf16 pack, ReLU on the packed pair: 8 VALU per 4 values
+                f32x2 s01 = (f32x2){acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
+                f32x2 s23 = (f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
+                if (a.relu == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
                 uint2 pk;
-                pk.x = pk_bf16(v0, v1);
-                pk.y = pk_bf16(v2, v3);
+                pk.x = pk_bf16(s01.x, s01.y);
+                pk.y = pk_bf16(s23.x, s23.y);
+                if (a.relu == 1 && !a.res) { pk.x = pk_relu_bf16(pk.x); pk.y = pk_relu_bf16(pk.y); }
                 *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
             }
         }
@@ -1008,10 +1014,10 @@ __global__ __launch_bounds__(256, 3) void conv_ring32_kernel(ConvArgs a) {
             const u32x4 rv = rres[it];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float lo = bf2f((uint16_t)(v[k] & 0xffff)) + bf2f((uint16_t)(rv[k] & 0xffff));
-                float hi = bf2f((uint16_t)(v[k] >> 16)) + bf2f((uint16_t)(rv[k] >> 16));
-                if (a.relu == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                v[k] = pk_bf16(lo, hi);
+                const f32x2 sum = (f32x2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)} +
+                                  (f32x2){__uint_as_float(rv[k] << 16), __uint_as_float(rv[k] & 0xffff0000u)};
+                v[k] = pk_bf16(sum.x, sum.y);
+                if (a.relu == 1) v[k] = pk_relu_bf16(v[k]);
             }
         }
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + off));
@@ -1107,7 +1113,9 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         const int hB = q >> 1, i = q & 1;
         const int m = pix0 + (i * 2 + (wave >> 2)) * 64 + hB * 32 + (wave & 3) * 8 + (lane >> 3);
         p_base[q] = 0; p_taps[q] = 0u;
-        if (m < a.M) {
+        if (a.pointwise) {
+            if (m < a.M) { p_base[q] = m * a.Cin * 2 + chunk * 16; p_taps[q] = 1u; }
+        } else if (m < a.M) {
             const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
             const int ho = r / a.Wo, wo = r - ho * a.Wo;
             const int hi0 = ho * a.stride - a.pad_top, wi0 = wo * a.stride - a.pad_left;
@@ -1325,16 +1333,14 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int p_local = wc * 64 + j * 32 + lr;
-                float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
-                float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
-                if (a.relu == 1 && !a.res) {
-                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                } else if (a.relu == 2) {
-                    v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
-                }
+                // packed adds (v_pk_add_f32), one-instruction bf16 pack, ReLU on the packed pair: 8 VALU per 4 values
+                f32x2 s01 = (f32x2){acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
+                f32x2 s23 = (f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
+                if (a.relu == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
                 uint2 pk;
-                pk.x = pk_bf16(v0, v1);
-                pk.y = pk_bf16(v2, v3);
+                pk.x = pk_bf16(s01.x, s01.y);
+                pk.y = pk_bf16(s23.x, s23.y);
+                if (a.relu == 1 && !a.res) { pk.x = pk_relu_bf16(pk.x); pk.y = pk_relu_bf16(pk.y); }
                 *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
             }
         }
@@ -1374,10 +1380,10 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
             const u32x4 rv = rres[it];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float lo = bf2f((uint16_t)(v[k] & 0xffff)) + bf2f((uint16_t)(rv[k] & 0xffff));
-                float hi = bf2f((uint16_t)(v[k] >> 16)) + bf2f((uint16_t)(rv[k] >> 16));
-                if (a.relu == 1) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                v[k] = pk_bf16(lo, hi);
+                const f32x2 sum = (f32x2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)} +
+                                  (f32x2){__uint_as_float(rv[k] << 16), __uint_as_float(rv[k] & 0xffff0000u)};
+                v[k] = pk_bf16(sum.x, sum.y);
+                if (a.relu == 1) v[k] = pk_relu_bf16(v[k]);
             }
         }
         if (ABL == 2 && v[0] != 0x12345u) continue;
@@ -1479,6 +1485,7 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
         return MD_ERR_SIZE;
     a.M = (int)M;
     a.cpt = a.Cin / 8;
+    a.pointwise = a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad_top == 0 && a.pad_left == 0 && a.H == a.Ho && a.W == a.Wo;
     hipStream_t s = (hipStream_t)stream;
     // variant: 0 = auto; 1 = register-staged 128x128; 2 = LDS-DMA 128x128; 3 = LDS-DMA 256(cout)x256(pix), 8 waves
     int variant = variant_override >= 0 ? variant_override : at->variant;
