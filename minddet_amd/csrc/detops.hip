@@ -499,6 +499,13 @@ __device__ __forceinline__ unsigned rf2bf(float f) {
     return u >> 16;
 }
 // rois [R,5] = (batch_idx, x1,y1,x2,y2) f32 ; out [R,P,P,C] bf16 ; one thread = 8 channels of one bin
+// two fp32 -> packed bf16, round-to-nearest-even, one instruction (gfx950)
+__device__ __forceinline__ unsigned rpk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
 __global__ void roi_align_kernel(RoiArgs a, const float *__restrict__ rois, int R, uint16_t *__restrict__ out,
                                  int *__restrict__ out_level) {
     const int cv = a.C / 8;
@@ -558,10 +565,10 @@ __global__ void roi_align_kernel(RoiArgs a, const float *__restrict__ rois, int 
         }
         const float inv = 1.f / (float)(g * g);
         uint4 o;
-        o.x = rf2bf(acc[0] * inv) | (rf2bf(acc[1] * inv) << 16);
-        o.y = rf2bf(acc[2] * inv) | (rf2bf(acc[3] * inv) << 16);
-        o.z = rf2bf(acc[4] * inv) | (rf2bf(acc[5] * inv) << 16);
-        o.w = rf2bf(acc[6] * inv) | (rf2bf(acc[7] * inv) << 16);
+        o.x = rpk_bf16(acc[0] * inv, acc[1] * inv);
+        o.y = rpk_bf16(acc[2] * inv, acc[3] * inv);
+        o.z = rpk_bf16(acc[4] * inv, acc[5] * inv);
+        o.w = rpk_bf16(acc[6] * inv, acc[7] * inv);
         *reinterpret_cast<uint4 *>(out + e * 8) = o;
     }
 }
@@ -638,10 +645,10 @@ __global__ __launch_bounds__(256) void roi_align_c32_kernel(RoiArgs a, const flo
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint4 o;
-            o.x = rf2bf(acc[q * 4 + 0].x * inv) | (rf2bf(acc[q * 4 + 0].y * inv) << 16);
-            o.y = rf2bf(acc[q * 4 + 1].x * inv) | (rf2bf(acc[q * 4 + 1].y * inv) << 16);
-            o.z = rf2bf(acc[q * 4 + 2].x * inv) | (rf2bf(acc[q * 4 + 2].y * inv) << 16);
-            o.w = rf2bf(acc[q * 4 + 3].x * inv) | (rf2bf(acc[q * 4 + 3].y * inv) << 16);
+            o.x = rpk_bf16(acc[q * 4 + 0].x * inv, acc[q * 4 + 0].y * inv);
+            o.y = rpk_bf16(acc[q * 4 + 1].x * inv, acc[q * 4 + 1].y * inv);
+            o.z = rpk_bf16(acc[q * 4 + 2].x * inv, acc[q * 4 + 2].y * inv);
+            o.w = rpk_bf16(acc[q * 4 + 3].x * inv, acc[q * 4 + 3].y * inv);
             dst[q] = o;
         }
     }

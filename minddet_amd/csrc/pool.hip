@@ -87,7 +87,7 @@ __global__ void upsample_add_kernel(const uint16_t *__restrict__ lat, const uint
         for (int q = 0; q < 4; ++q) {
             const float lo = pbf2f(a[q] & 0xffffu) + pbf2f(b[q] & 0xffffu);
             const float hi = pbf2f(a[q] >> 16) + pbf2f(b[q] >> 16);
-            o[q] = pf2bf(lo) | (pf2bf(hi) << 16);
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o[q]) : "v"(lo), "v"(hi));  // RNE pack, one instruction
         }
         *reinterpret_cast<u32x4 *>(y + e * 8) = o;
     }
