@@ -667,25 +667,32 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------
 constexpr int HT_H = 8, HT_W = 16, HALO_W = HT_W + 2, HALO_ROWS = (HT_H + 2) * HALO_W;  // 180 halo pixels
 constexpr int HALO_DMAS = (HALO_ROWS + 7) / 8;                                           // 23 x 1 KiB
-constexpr int HALO_BYTES = HALO_DMAS * 1024, WSTAGE_BYTES = 128 * ROWB;
+constexpr int HALO_BYTES = HALO_DMAS * 1024;
 
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a, int tiles_x, int tiles_y) {
-    constexpr int CT = 128, PT = HT_H * HT_W, FC = 2, FP = 2;
+// CT = cout tile (128: waves 2 x 2, each 64 couts x 64 pixels; 64: waves 1 x 4, each 64 couts x 32 pixels).
+// ONE_HALO: a single halo buffer, refilled (exposed, but four workgroups share the CU) when the 64-channel chunk
+// changes: 2 x 8 KiB weight stages + 23 KiB halo = 39 KiB -> four workgroups per CU for CT 64.
+template <int CT, bool ONE_HALO>
+__global__ __launch_bounds__(256, CT == 64 ? 4 : 2) void conv3x3_halo_kernel(ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int PT = HT_H * HT_W, WC = CT / 64, WP = 4 / WC, FC = 2, FP = 4 / WP;
+    static_assert(WC * WP == 4 && WC * FC * 32 == CT && WP * FP * 32 == PT, "wave grid must cover the tile");
+    constexpr int WSTAGE = CT * ROWB;
     constexpr int EP_STRIDE = CT * 2 + 16;
     constexpr unsigned OOR = 0x80000000u;
     typedef __attribute__((address_space(3))) void lds_void;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *Wst = smem;                      // 2 weight stages
-    char *Hst = smem + 2 * WSTAGE_BYTES;   // 2 halo stages
+    char *Wst = smem;                // 2 weight stages
+    char *Hst = smem + 2 * WSTAGE;   // 1 or 2 halo stages
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wc = wave >> 1, wp = wave & 1;
+    const int wc = wave / WP, wp = wave % WP;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int ct = slot % a.n_ctiles, pt = xcd * a.pt_per_xcd + slot / a.n_ctiles;
     if (pt >= a.n_ptiles) return;
     const int cout0 = ct * CT;
     const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, n = pt / (tiles_x * tiles_y);
     const int y0 = ty * HT_H, x0 = tx * HT_W;
+    const float bias_early = tid < CT ? a.bias[cout0 + tid] : 0.f;  // parked in LDS for the epilogue (see conv_igemm_kernel)
 
     __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
@@ -709,8 +716,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a, int ti
     const int n_chunks = a.Cin / 64;
     auto dma_weights = [&](int step, int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(Wst + buf * WSTAGE_BYTES + (wrow + 32 * i) * ROWB), 16,
+        for (int i = 0; i < CT / 32; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(Wst + buf * WSTAGE + (wrow + 32 * i) * ROWB), 16,
                                                      a_off0 + i * (32 * a.Kpad * 2), step * (BK * 2), 0, 0);
     };
     auto dma_halo_piece = [&](int c, int j, int buf) {  // piece j (0..5) of chunk c's halo
@@ -736,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a, int ti
     int r0[FP];
 #pragma unroll
     for (int j = 0; j < FP; ++j) {
-        const int p = wp * 64 + j * 32 + lr;
+        const int p = (wp * FP + j) * 32 + lr;
         r0[j] = (p >> 4) * HALO_W + (p & 15);
     }
 
@@ -747,13 +754,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a, int ti
     const int n_steps = n_chunks * 9;
     int c = 0, t = 0;  // chunk / tap of the step being computed
     for (int s_ = 0; s_ < n_steps; ++s_) {
+        if (ONE_HALO && t == 0 && c > 0) {
+            __syncthreads();  // every wave has finished the last tap of chunk c - 1: the halo buffer may be refilled
+#pragma unroll
+            for (int j = 0; j < 6; ++j) dma_halo_piece(c, j, 0);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (s_ + 1 < n_steps) dma_weights(s_ + 1, (s_ + 1) & 1);
-        if (t < 6 && c + 1 < n_chunks) dma_halo_piece(c + 1, t, (c + 1) & 1);
+        if (!ONE_HALO && t < 6 && c + 1 < n_chunks) dma_halo_piece(c + 1, t, (c + 1) & 1);
         // compute step (c, t): A from the weight stage, B from the halo stage at the tap's shifted rows
-        const char *Wb = Wst + (s_ & 1) * WSTAGE_BYTES;
-        const char *Hb = Hst + (c & 1) * HALO_BYTES;
+        const char *Wb = Wst + (s_ & 1) * WSTAGE;
+        const char *Hb = Hst + (ONE_HALO ? 0 : (c & 1) * HALO_BYTES);
         const int radd = (t / 3) * HALO_W + (t % 3);
         int b_off[FP];
 #pragma unroll
@@ -796,16 +808,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs a, int ti
         }
     }
     char *E = smem;
+    float *bias_lds = reinterpret_cast<float *>(smem + PT * EP_STRIDE);
+    if (tid < CT) bias_lds[tid] = bias_early;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < FC; ++i) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c_local = (wc * FC + i) * 32 + 8 * g + 4 * lh;
-            const float4 bv = *reinterpret_cast<const float4 *>(a.bias + cout0 + c_local);
+            const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + c_local);
 #pragma unroll
             for (int j = 0; j < FP; ++j) {
                 const int p_local = (wp * FP + j) * 32 + lr;
-                // packed adds (v_pk_add_f32), one-instruction bf16 pack, ReLU on the packed pair: 8 VALU per 4 values
                 f32x2 s01 = (f32x2){acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
                 f32x2 s23 = (f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
                 if (a.relu == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
@@ -1036,18 +1050,21 @@ static int launch_conv_ring32(ConvArgs &a, hipStream_t s) {
 }
 
 
+template <int CT, bool ONE_HALO>
 static int launch_conv3x3_halo(ConvArgs &a, hipStream_t s) {
     g_last_kernel = MD_CONV_KERNEL_HALO;
     const int tiles_x = (a.W + HT_W - 1) / HT_W, tiles_y = (a.H + HT_H - 1) / HT_H;
-    a.n_ctiles = (a.Cout + 127) / 128;
+    a.n_ctiles = (a.Cout + CT - 1) / CT;
     a.n_ptiles = a.N * tiles_x * tiles_y;
     a.pt_per_xcd = (a.n_ptiles + 7) / 8;
     const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
-    const int lds = 2 * WSTAGE_BYTES + 2 * HALO_BYTES;  // 79,872 B: two workgroups per CU
-    if (hipFuncSetAttribute((const void *)conv3x3_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-        return MD_ERR_HIP;
-    hipLaunchKernelGGL(conv3x3_halo_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a, tiles_x, tiles_y);
+    const int stage = 2 * CT * ROWB + (ONE_HALO ? 1 : 2) * HALO_BYTES;
+    const int ep = HT_H * HT_W * (CT * 2 + 16) + CT * 4;  // epilogue image + bias copy
+    const int lds = stage > ep ? stage : ep;
+    auto k = conv3x3_halo_kernel<CT, ONE_HALO>;
+    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, a, tiles_x, tiles_y);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
@@ -1510,7 +1527,11 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     const double t_sb = (double)(sb_blocks / 1024) * 4.0 + (sb_blocks % 1024 ? 1.5 + 2.5 * sb_last : 0.0);
     const bool pp_ok = fast && dma_ok && a.Cout % 256 == 0 && a.Kpad >= 1024 && pp_blocks >= 128 && t_pp <= t_sb;
     if (variant == 0 && pp_ok) return launch_conv_pingpong<0>(a, s);
-    if (halo_ok && !a.res_up && variant == 11) return launch_conv3x3_halo(a, s);  // superseded by the two paths around it
+    if (halo_ok && !a.res_up && variant == 11) return launch_conv3x3_halo<128, false>(a, s);  // superseded by the paths around it
+    // 64-cout tiles of the halo kernel at four workgroups per CU (variant 27; auto for Cout <= 64)
+    const bool halo64_ok = dma_ok && !a.adv && a.korder == 1 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 &&
+                           a.Cin % 64 == 0 && a.Cout % 64 == 0 && cout_pad % 64 == 0 && !a.res_up;
+    if (halo64_ok && (variant == 27 || (variant == 0 && ctile == 64))) return launch_conv3x3_halo<64, true>(a, s);
     if (variant == 11) variant = 2;
     if (variant == 15 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0>(a, s);  // 256x256 ping-pong, 8 waves
     if (variant == 22 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0, 1>(a, s);  // same, 16x16x32 MFMA

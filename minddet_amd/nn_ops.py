@@ -73,7 +73,7 @@ def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, relu=False, cin_pad_t
     if korder is None:
         # 3x3 / stride 1 / pad 1 on >= 64 channels with >= 72 output channels runs on the halo-reuse kernel, which
         # wants the (ci/64, tap, ci%64) K order; everything else keeps (tap, ci)
-        halo = kh == 3 and kw == 3 and stride == 1 and pad == 1 and cin_p % 64 == 0 and cout_o > 64
+        halo = kh == 3 and kw == 3 and stride == 1 and pad == 1 and cin_p % 64 == 0 and cout_o >= 64
         korder = 1 if halo else KORDER_DEFAULT
     if korder == 1:  # (ci/64, kh, kw, ci%64)
         wp = wp.reshape(cout_p, kh, kw, cin_p // 64, 64).permute(0, 3, 1, 2, 4).contiguous()

@@ -31,10 +31,12 @@ CASES = [
     ("halo_big", 1, 100, 168, 256, 256, 3, 1, 1, True, False, False),
     ("pp_1x1_1024_512_res", 2, 50, 84, 1024, 512, 1, 1, 0, True, True, True),
     ("pp_3x3_s2_128_256", 1, 51, 85, 128, 256, 3, 2, 1, True, False, True),
+    ("halo64_128_64_res", 2, 19, 37, 128, 64, 3, 1, 1, True, True, True),
+    ("halo64_192_192", 1, 24, 33, 192, 192, 3, 1, 1, True, False, False),
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 15, 16, 20, 22])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 15, 16, 20, 22, 27])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_conv_vs_torch_fp32(case, variant):
     from minddet_amd import nn_ops
@@ -48,7 +50,7 @@ def test_conv_vs_torch_fp32(case, variant):
     if use_bn:
         bn = (torch.rand((Cout,), generator=g) + 0.5, torch.randn((Cout,), generator=g) * 0.1,
               torch.randn((Cout,), generator=g) * 0.1, torch.rand((Cout,), generator=g) + 0.5, 1e-5)
-    korder = 1 if (variant in (2, 5, 11, 16) and Cin % 64 == 0 and k > 1) else 0
+    korder = 1 if (variant in (2, 5, 11, 16, 27) and Cin % 64 == 0 and k > 1) else 0
     if variant == 16:
         variant = 15  # the ping-pong kernel on korder-1 weights
     pc = nn_ops.pack_conv(w, bias=bias, bn=bn, stride=stride, pad=pad, relu=relu, korder=korder).to(DEV)
