@@ -85,7 +85,9 @@ __device__ __forceinline__ unsigned pk_relu_bf16(unsigned v) {  // max(x, 0) on 
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
+// SiLU with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division (v_div_scale / fmas / fixup: ~10 VALU per
+// value, 64 values per lane in an epilogue that is VALU-bound at four workgroups per CU); the result is rounded to bf16.
+__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 constexpr int BK = 64;
 constexpr int ROWB = BK * 2;  // bytes per LDS tile row
