@@ -172,6 +172,10 @@ enum {
     MD_CONV_KERNEL_OTHER = 6            /* A/B variants */
 };
 int md_conv2d_last_kernel(void);
+/* md_conv2d runs a batch whose activation tensor exceeds `bytes` (default and maximum: 2 GiB - 64 KiB, the reach of the
+ * kernels' 32-bit LDS-DMA offsets) as consecutive image chunks on the same stream.  Returns the previous limit; tests
+ * lower it to exercise the chunked path on small tensors. */
+long long md_conv2d_set_chunk_limit(long long bytes);
 
 /* ------------------------------------------------------------------------------------------
  * Streaming NHWC bf16 helpers between convs

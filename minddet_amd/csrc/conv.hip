@@ -97,6 +97,8 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((c
 // id of the kernel the dispatcher chose for this host thread's last md_conv2d call (md_conv2d_last_kernel): lets a
 // profiler-less caller (bench.py) attribute per-launch timings to kernels
 static thread_local int g_last_kernel = 0;
+// activation bytes above which md_conv2d slices the batch (the kernels' 32-bit DMA offsets); lowered only by tests
+static long long g_chunk_limit = 0x7fff0000LL;
 
 // 16 zero bytes: the source of every out-of-image / past-K chunk when staging with LDS-DMA
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
@@ -1440,6 +1442,11 @@ using namespace md;
 // Required weight padding for a given Cout (the tile the dispatcher will pick): exported so the
 // host packer pads consistently.
 extern "C" int md_conv2d_last_kernel(void) { return g_last_kernel; }
+extern "C" long long md_conv2d_set_chunk_limit(long long bytes) {
+    const long long old = g_chunk_limit;
+    g_chunk_limit = bytes > 0 && bytes < 0x7fff0000LL ? bytes : 0x7fff0000LL;
+    return old;
+}
 
 extern "C" int md_conv2d_cout_tile(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 
@@ -1451,6 +1458,32 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
         return MD_ERR_ARG;
     if (!ndims || !shapes || ndims[0] != 4 || ndims[1] != 2 || ndims[4] != 4) return MD_ERR_ARG;
     const md_conv2d_attrs *at = (const md_conv2d_attrs *)extra;
+    // The LDS-DMA kernels address the activation tensor with 32-bit byte offsets.  A batch whose input (or output /
+    // residual, which the kernels address with 64-bit math but the same image split applies to) exceeds 2 GiB is run
+    // as consecutive image chunks on the same stream: every tensor of the call is sliced along N.
+    {
+        const long long n_img = shapes[0][0];
+        const long long x_img = shapes[0][1] * shapes[0][2] * shapes[0][3] * 2;
+        if (n_img > 1 && x_img > 0 && x_img < g_chunk_limit && n_img * x_img >= g_chunk_limit && shapes[4][0] == n_img &&
+            (!params[3] || (ndims[3] == 4 && shapes[3][0] == n_img))) {
+            const long long per = g_chunk_limit / x_img;  // images per chunk (>= 1)
+            const long long y_img = shapes[4][1] * shapes[4][2] * shapes[4][3] * 2;
+            const long long r_img = params[3] ? shapes[3][1] * shapes[3][2] * shapes[3][3] * 2 : 0;
+            for (long long n0 = 0; n0 < n_img; n0 += per) {
+                const long long nn = n_img - n0 < per ? n_img - n0 : per;
+                int64_t sx[4] = {nn, shapes[0][1], shapes[0][2], shapes[0][3]};
+                int64_t sy[4] = {nn, shapes[4][1], shapes[4][2], shapes[4][3]};
+                int64_t sr[4] = {nn, 0, 0, 0};
+                if (params[3]) { sr[1] = shapes[3][1]; sr[2] = shapes[3][2]; sr[3] = shapes[3][3]; }
+                int64_t *sh2[5] = {sx, shapes[1], shapes[2], params[3] ? sr : shapes[3], sy};
+                void *p2[5] = {(char *)params[0] + n0 * x_img, params[1], params[2],
+                               params[3] ? (void *)((char *)params[3] + n0 * r_img) : nullptr, (char *)params[4] + n0 * y_img};
+                const int rc = md_conv2d(nparam, p2, ndims, sh2, dtypes, stream, extra);
+                if (rc != MD_OK) return rc;
+            }
+            return MD_OK;
+        }
+    }
     int variant_override = -1;
     ConvArgs a;
     a.x = (const uint16_t *)params[0];

@@ -168,3 +168,27 @@ def test_stem_pool_vs_torch_fp32(shape):
     y2 = nn_ops.maxpool2d(nn_ops.conv2d(xb, pc), 3, 2, 1, zero_pad=True).float().cpu()
     assert ((y - y2).abs() <= 1.2e-2 * ref.abs() + 1.2e-2 * rms).all()
     assert (y == y2).float().mean() > 0.98
+
+
+def test_conv_batch_chunking_is_bit_identical():
+    """A batch above the 32-bit DMA reach is run as image chunks; with the limit lowered the chunked result must equal
+    the single-launch result bit for bit (residual and all)."""
+    import ctypes
+
+    from minddet_amd import _lib, nn_ops
+
+    g = torch.Generator().manual_seed(21)
+    wt = torch.randn((128, 64, 3, 3), generator=g) * 0.05
+    pc = nn_ops.pack_conv(wt, bias=torch.randn((128,), generator=g) * 0.1, stride=1, pad=1, relu=True).to(DEV)
+    x = torch.randn((5, 20, 24, 64), generator=g).to(torch.bfloat16).to(DEV)
+    r = torch.randn((5, 20, 24, 128), generator=g).to(torch.bfloat16).to(DEV)
+    y0 = nn_ops.conv2d(x, pc, residual=r)
+    fn = _lib.lib().md_conv2d_set_chunk_limit
+    fn.restype, fn.argtypes = ctypes.c_longlong, [ctypes.c_longlong]
+    old = fn(2 * 20 * 24 * 64 * 2 + 1)  # two images per chunk -> 3 launches
+    try:
+        y1 = nn_ops.conv2d(x, pc, residual=r)
+    finally:
+        fn(old)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
