@@ -131,8 +131,12 @@ typedef struct md_conv2d_attrs {
     int32_t kh, kw, stride, pad; /* square stride / symmetric zero padding */
     int32_t relu;                /* activation: 0 none; 1 ReLU applied after bias (+ residual);
                                     2 SiLU applied after bias, BEFORE the residual add (x + act(conv(x))) */
-    int32_t variant;             /* 0 = auto (default). Tile/staging variant for A/B measurements:
-                                    1 register-staged 128x128, 2 LDS-DMA 128x128, 3 LDS-DMA 256x256 */
+    int32_t variant;             /* 0 = auto (default: cost model in csrc/conv.hip).  Pins a kernel for A/B measurements:
+                                    1 register-staged 128x128, 2 / 20 LDS-DMA 128x128 with two / one staging buffer,
+                                    5 128x128 on 16x16x32 MFMA, 11 / 27 halo-reuse kernel with 128- / 64-cout tiles,
+                                    15 / 22 256x256 ping-pong kernel (32x32x16 / 16x16x32 MFMA); a variant whose
+                                    preconditions do not hold falls back to the generic kernel.  17-19 and 25 are timing /
+                                    stamp diagnostics of tools/*.py and do NOT compute the convolution. */
     /* generalised addressing, used when adv != 0 (all zero = plain conv).  The op then computes, for
      * ho < sub_h, wo < sub_w:  y[n, ho*out_stride + out_off_y, wo*out_stride + out_off_x, c_off + c] =
      * act(bias[c] + sum x[n, ho*stride - pad_top + kh, wo*stride - pad_left + kw, ci] * w[c,kh,kw,ci]), c < cout.
@@ -168,7 +172,7 @@ enum {
     MD_CONV_KERNEL_IGEMM_128 = 2,       /* conv_igemm_kernel 128x128, LDS-DMA, Cin % 64 == 0 */
     MD_CONV_KERNEL_IGEMM_SMALL_COUT = 3,/* conv_igemm_kernel 64- / 32-cout tiles */
     MD_CONV_KERNEL_IGEMM_GENERIC_K = 4, /* conv_igemm_kernel generic K walk (the 7x7 stem) */
-    MD_CONV_KERNEL_HALO = 5,            /* conv3x3_halo_kernel (variant 11) */
+    MD_CONV_KERNEL_HALO = 5,            /* conv3x3_halo_kernel (3x3 layers with Cout <= 64; variant 11 / 27) */
     MD_CONV_KERNEL_OTHER = 6            /* A/B variants */
 };
 int md_conv2d_last_kernel(void);

@@ -53,7 +53,7 @@ struct ConvArgs {
     int os, oy, ox, c_off;  // output pixel (ho*os + oy, wo*os + ox), channels [c_off, c_off + Cout)
     int adv;                // 0: plain (off = m*Cout + c)
     int korder;             // 0: K = (tap, ci); 1: K = (ci/64, tap, ci%64)  (MODE 2 only)
-    int single_buf;         // PIPE 0 LDS-DMA loop with ONE staging buffer (short-K layers: more workgroups per CU)
+    int single_buf;         // LDS-DMA K loop with ONE staging buffer (four resident workgroups per CU)
     int pointwise;          // 1x1 / stride 1 / pad 0 (input pixel index == output pixel index)
     int bias_lds_off;       // byte offset of the CT-float bias copy in LDS (past the staging buffers and the epilogue image)
     int stamp;              // diagnostic (variant 25): a mid-grid workgroup overwrites the first output bytes with s_memtime stamps
@@ -113,38 +113,28 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 
 //         activation row (tap-validity bit -> select the out-of-range offset) and none on weights.
 // The LDS image of a DMA is lane-linear per wave instruction (8 rows x 128 B), so the XOR swizzle is
 // applied to the per-lane SOURCE chunk and to the fragment reads, never to the destination.
-// PIPE 0: two LDS stages, every wave waits for its DMAs (vmcnt 0) at the barrier of each K tile.
-// PIPE 1: three-stage LDS ring, prefetch distance two tiles, COUNTED vmcnt (one stage stays in flight across
-//         the barrier), and the two waves that share a SIMD (w, w+4) issue their DMAs at opposite ends of
-//         the iteration, so one wave's DMA issue overlaps its partner's MFMA cluster.  MODE 2, 8 waves.
+// K loop: ONE LDS staging buffer by default (a.single_buf; 34 KiB -> four resident workgroups per CU whose serial
+// DMA -> MFMA -> epilogue chains overlap each other), or two with the next tile's DMA issued before the MFMAs (variant 2).
+// Measured and removed in r01: 3-stage ring with counted vmcnt, producer/consumer waves, 4-stage
+// BK-32 ring, DMA issue interleaved with the MFMA clusters, 256x256 tile on this loop.
 // MF 0: v_mfma_f32_32x32x16_bf16 (FC x FP tiles of 32x32 per wave); MF 1: v_mfma_f32_16x16x32_bf16 (2FC x 2FP
 // tiles of 16x16, K 32 per instruction): same LDS traffic and cycles per flop, but the chip holds a higher
 // clock on the 16x16 shape under load (MI355X_MICROARCH.md, DVFS give-back item 7).
-template <int NT, int WC, int WP, int FC, int FP, int MODE, int PIPE = 0, int MF = 0>
+template <int NT, int WC, int WP, int FC, int FP, int MODE, int MF = 0>
 __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr bool GLDS = MODE != 0;
-    static_assert(PIPE == 0 || PIPE == 3 || (MODE == 2 && NT == 512), "the ring variants are built for the LDS-DMA fast path, 8 waves");
-    // PIPE 2: PRODUCER / CONSUMER waves.  Measured on the PIPE-0 kernel (tools/conv_ab.py ablations, r01): staging
-    // alone takes ~60 % of the kernel time, the MFMAs alone ~35 %, and the two do not overlap -- an in-order wave
-    // that is stalled issuing LDS-DMA (TA back-pressure) cannot issue its MFMAs.  Here waves [0, NT/128) only
-    // compute and waves [NT/128, NT/64) only stage: one barrier per K tile hands a landed stage over.
-    constexpr bool SPEC = PIPE == 2;
-    constexpr int NTC = SPEC ? NT / 2 : NT;  // threads that compute (and threads that stage)
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
-    constexpr int RPP = (PIPE == 2 ? NT / 2 : NT) / 8;     // tile rows staged per pass of the staging threads
+    constexpr int RPP = NT / 8;                            // tile rows staged per pass of the workgroup
     constexpr int A_ROWS = CT / RPP, B_ROWS = PT / RPP;    // 16-B chunks per thread per tile
     constexpr int TILE_BYTES = (CT + PT) * ROWB;
     constexpr int EP_STRIDE = CT * 2 + 16;                 // epilogue image row stride (bytes)
     constexpr unsigned OOR = 0x80000000u;                  // byte offset past any buffer (< 2 GiB): reads as 0
-    static_assert(WC * WP * 64 == (PIPE == 2 ? NT / 2 : NT), "wave grid must cover the compute waves");
+    static_assert(WC * WP * 64 == NT, "wave grid must cover the workgroup");
     static_assert(CT % RPP == 0 && PT % RPP == 0, "tile rows must be a multiple of the staging pass");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool is_loader = SPEC && __builtin_amdgcn_readfirstlane(tid) >= NTC;
-    const int cwave = SPEC ? (wave & (NTC / 64 - 1)) : wave;  // index inside the compute (or staging) group
-    const int wc = cwave / WP, wp = cwave % WP;
-    const int stid = SPEC ? (tid & (NTC - 1)) : tid;           // staging thread index
+    const int wc = wave / WP, wp = wave % WP;
     // XCD-aware tile map (workgroups are dealt round-robin over the 8 XCDs, each with a private L2):
     // every XCD owns a CONTIGUOUS range of pixel tiles, and inside it the cout tile varies fastest, so the
     // workgroups that share an activation tile (and the 3x3 halo rows of its neighbours) hit the same L2.
@@ -161,8 +151,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
 
     // this thread stages rows row0 + RPP*i; physical 16-B slot (tid & 7) of the row holds LOGICAL k-chunk
     // `chunk` (the swizzle term (row>>1)&7 is the same for all of a thread's rows because RPP % 16 == 0)
-    const int row0 = stid >> 3;
-    const int chunk = GLDS ? ((stid & 7) ^ ((row0 >> 1) & 7)) : (stid & 7);
+    const int row0 = tid >> 3;
+    const int chunk = GLDS ? ((tid & 7) ^ ((row0 >> 1) & 7)) : (tid & 7);
     const int n_taps = a.kh * a.kw;
     const int nk = a.Kpad / BK;
 
@@ -239,7 +229,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
         a_off0 = ((cout0 + row0) * a.Kpad + chunk * 8) * 2;
     }
-    const int wrow = (stid >> 6) * 8;  // first row of this wave's 8-row group inside a staging pass
+    const int wrow = wave * 8;  // first row of this wave's 8-row group inside a staging pass
     auto dma_tile = [&](int kt, int buf) {
         typedef __attribute__((address_space(3))) void lds_void;
         char *A = smem + buf * TILE_BYTES, *B = A + CT * ROWB;
@@ -275,34 +265,6 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(B + (wrow + RPP * i) * ROWB), 16, (int)voff, 0, 0, 0);
             }
             advance_k();
-        }
-    };
-
-    // MODE 2 only: the same staging split into slices (one weight row group + one activation row group each), so
-    // that the DMA issue can be spread between the MFMA clusters of the tile being computed (PIPE 3).
-    auto dma_slice = [&](int kt, int buf, int q) {
-        typedef __attribute__((address_space(3))) void lds_void;
-        char *A = smem + buf * TILE_BYTES, *B = A + CT * ROWB;
-        if (q < A_ROWS)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(A + (wrow + RPP * q) * ROWB), 16,
-                                                     a_off0 + q * (RPP * a.Kpad * 2), kt * (BK * 2), 0, 0);
-        if (q < B_ROWS) {
-            const int soff = ((s_kh * a.W + s_kw) * a.Cin + s_cc0 * 8) * 2;
-            const unsigned voff = ((p_taps[q] >> s_tap) & 1u) ? (unsigned)(p_base[q] + soff) : OOR;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(B + (wrow + RPP * q) * ROWB), 16, (int)voff, 0, 0, 0);
-        }
-    };
-    auto advance_walk = [&]() {
-        if (a.korder == 0) {
-            s_cc0 += 8;
-            if (s_cc0 == a.cpt) {
-                s_cc0 = 0; ++s_tap;
-                if (++s_kw == a.kw) { s_kw = 0; ++s_kh; }
-            }
-        } else {
-            ++s_tap;
-            if (++s_kw == a.kw) { s_kw = 0; ++s_kh; }
-            if (s_tap == n_taps) { s_tap = 0; s_kh = 0; s_kw = 0; s_cc0 += 8; }
         }
     };
 
@@ -386,101 +348,9 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
 
     auto compute_tile = [&](int buf) {
         if constexpr (MF == 1) compute_tile16(buf);
-        else if constexpr (MF == 2) { /* ablation: staging only */ }
         else compute_tile32(buf);
     };
 
-    if constexpr (PIPE == 3) {
-        // Measured (r01, tools/ubench/dma_bench.hip + ablations): an LDS-DMA instruction blocks its issuing wave for
-        // ~150 cycles, and MFMAs only overlap that if they were issued BEFORE it.  So the DMAs of tile kt+1 are
-        // issued in slices right after each MFMA cluster of tile kt (the matrix pipe drains the cluster while the
-        // wave sits in the DMA issue), instead of as one burst in front of the tile.
-        static_assert(MODE == 2 && MF == 0, "interleaved issue is built on the fast path");
-        constexpr int NSL = A_ROWS > B_ROWS ? A_ROWS : B_ROWS;  // slices per tile
-        static_assert(NSL <= BK / 16 * 2, "at most two slices per k-step");
-        dma_tile(0, 0);
-        for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const char *T = smem + (kt & 1) * TILE_BYTES;
-            const bool more = kt + 1 < nk;
-            const int nb = (kt + 1) & 1;
-            bf16x8 fa[2][FC], fb[2][FP];
-#pragma unroll
-            for (int i = 0; i < FC; ++i) fa[0][i] = *reinterpret_cast<const bf16x8 *>(T + fa_off[0] + i * 32 * ROWB);
-#pragma unroll
-            for (int j = 0; j < FP; ++j) fb[0][j] = *reinterpret_cast<const bf16x8 *>(T + fb_off[0] + j * 32 * ROWB);
-#pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-                if (kk + 1 < BK / 16) {
-#pragma unroll
-                    for (int i = 0; i < FC; ++i) fa[(kk + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(T + fa_off[kk + 1] + i * 32 * ROWB);
-#pragma unroll
-                    for (int j = 0; j < FP; ++j) fb[(kk + 1) & 1][j] = *reinterpret_cast<const bf16x8 *>(T + fb_off[kk + 1] + j * 32 * ROWB);
-                }
-#pragma unroll
-                for (int i = 0; i < FC; ++i)
-#pragma unroll
-                    for (int j = 0; j < FP; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk & 1][i], fb[kk & 1][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) {
-                    constexpr int PER = (NSL + BK / 16 - 1) / (BK / 16);
-#pragma unroll
-                    for (int q = kk * PER; q < (kk + 1) * PER && q < NSL; ++q) dma_slice(kt + 1, nb, q);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (more) advance_walk();
-        }
-        __syncthreads();
-    } else if constexpr (PIPE == 2) {
-        // 4-stage LDS ring (128 KiB), one workgroup per CU.  Staging waves run up to three tiles ahead of the
-        // compute waves and wait with COUNTED vmcnt (two stages may stay in flight across the barrier).
-        constexpr int NST = 4, DPS = A_ROWS + B_ROWS;  // stages; DMA instructions per stage per staging wave
-        static_assert(DPS == 8, "counted waits below assume 8 DMAs per stage");
-        if (is_loader) {
-            dma_tile(0, 0);
-            if (nk > 1) dma_tile(1, 1);
-            if (nk > 2) dma_tile(2, 2);
-            if (nk > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();  // stage 0 landed
-        for (int kt = 0; kt < nk; ++kt) {
-            if (is_loader) {
-                if (kt + 3 < nk) dma_tile(kt + 3, (kt + 3) & (NST - 1));  // refills the buffer compute(kt-1) released
-                const int ahead = min(nk - 1, kt + 3) - (kt + 1);            // stages issued beyond kt+1
-                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                compute_tile(kt & (NST - 1));
-            }
-            __syncthreads();  // stage kt+1 landed and published; stage kt released
-        }
-    } else if constexpr (PIPE == 1) {
-        constexpr int DMA_PER_STAGE = A_ROWS + B_ROWS;  // LDS-DMA instructions a wave issues per stage
-        static_assert(DMA_PER_STAGE == 6, "the counted wait below is written for 6 DMAs per stage");
-        const bool early = __builtin_amdgcn_readfirstlane(tid) < NT / 2;  // waves 0-3 vs their SIMD partners 4-7
-        dma_tile(0, 0);
-        if (nk > 1) dma_tile(1, 1);
-        int rd = 0, wr = 2;  // ring positions of the stage being computed / refilled
-        for (int kt = 0; kt < nk; ++kt) {
-            // stage kt has landed when at most the NEXT stage's DMAs of this wave are still in flight
-            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // publishes stage kt; everyone has finished computing stage kt-1
-            const bool refill = kt + 2 < nk;
-            if (early && refill) dma_tile(kt + 2, wr);
-            compute_tile(rd);
-            if (!early && refill) dma_tile(kt + 2, wr);
-            rd = rd == 2 ? 0 : rd + 1;
-            wr = wr == 2 ? 0 : wr + 1;
-        }
-        __syncthreads();
-    } else
     if constexpr (GLDS) {
         if (a.single_buf) {
             // short-K, HBM/latency-bound layers: half the LDS -> twice the resident workgroups, whose epilogues
@@ -501,7 +371,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
             // wave has finished reading the other buffer in the previous iteration -> safe to refill it
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (kt + 1 < nk && (MF != 3 || kt == 0)) dma_tile(kt + 1, (kt + 1) & 1);  // MF 3 = ablation: compute only
+            if (kt + 1 < nk) dma_tile(kt + 1, (kt + 1) & 1);
             compute_tile(kt & 1);
         }
         __syncthreads();
@@ -550,9 +420,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
     float *bias_lds = reinterpret_cast<float *>(smem + a.bias_lds_off);
     if (tid < CT) bias_lds[tid] = bias_early;
     __syncthreads();
-    if (is_loader) {
-        // staging waves hold no accumulators
-    } else if constexpr (MF == 1) {
+    if constexpr (MF == 1) {
 #pragma unroll
         for (int i = 0; i < 2 * FC; ++i) {
             const int c_local = (wc * FC * 2 + i) * 16 + 4 * lq;  // 4 consecutive couts
@@ -630,17 +498,17 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
     }
 }
 
-template <int NT, int WC, int WP, int FC, int FP, int MODE, int PIPE = 0, int MF = 0>
+template <int NT, int WC, int WP, int FC, int FP, int MODE, int MF = 0>
 static int launch_conv(ConvArgs &a, hipStream_t s) {
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
-    g_last_kernel = MODE == 1 ? MD_CONV_KERNEL_IGEMM_GENERIC_K : (CT == 128 && PT == 128 && PIPE == 0 ? MD_CONV_KERNEL_IGEMM_128 :
+    g_last_kernel = MODE == 1 ? MD_CONV_KERNEL_IGEMM_GENERIC_K : (CT == 128 && PT == 128 ? MD_CONV_KERNEL_IGEMM_128 :
                     (CT < 128 ? MD_CONV_KERNEL_IGEMM_SMALL_COUT : MD_CONV_KERNEL_OTHER));
     a.n_ctiles = (a.Cout + CT - 1) / CT;
     a.n_ptiles = (a.M + PT - 1) / PT;
     // one staging buffer is enough when the whole K fits one tile (1x1 convs on 64 channels): more
     // workgroups per CU for the HBM-bound layers
-    if (PIPE != 0 || MODE == 0) a.single_buf = 0;
-    const int nbuf = PIPE == 2 ? 4 : (PIPE == 1 ? 3 : (a.Kpad / BK > 1 && !a.single_buf ? 2 : 1));
+    if (MODE == 0) a.single_buf = 0;
+    const int nbuf = a.Kpad / BK > 1 && !a.single_buf ? 2 : 1;
     const int tile_bytes = (CT + PT) * ROWB * nbuf;
     constexpr int ep_bytes = PT * (CT * 2 + 16);
     a.bias_lds_off = tile_bytes > ep_bytes ? tile_bytes : ep_bytes;
@@ -648,7 +516,7 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
     a.pt_per_xcd = (a.n_ptiles + 7) / 8;
     const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
-    auto k = conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, PIPE, MF>;
+    auto k = conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, MF>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return MD_ERR_HIP;
@@ -856,203 +724,6 @@ __global__ __launch_bounds__(256, CT == 64 ? 4 : 2) void conv3x3_halo_kernel(Con
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + off));
     }
 }
-
-// ------------------------------------------------------------------------------------------------------------
-// Deep-prefetch variant of the LDS-DMA fast path: K tiles of 32 channels (64-B LDS rows), a FOUR-stage ring in the
-// same 64 KiB (so still two workgroups per CU), prefetch distance three tiles, counted vmcnt.  Motivation (r01
-// measurements): a batch of LDS-DMAs takes ~1200-1500 cycles from issue to landed under load, the MFMA work of a
-// 64-deep tile is 512 cycles per wave, so with one tile of prefetch the loop is latency-bound; three tiles in
-// flight per workgroup (96 KiB per CU) cover it.  Same contract as conv_igemm_kernel MODE 2 (Cin % 64 == 0).
-// ------------------------------------------------------------------------------------------------------------
-constexpr int RB = 32, RROWB = RB * 2;  // ring tile depth (channels) and LDS row bytes
-__device__ __forceinline__ int rswz(int row, int chunk) { return row * RROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
-
-__global__ __launch_bounds__(256, 3) void conv_ring32_kernel(ConvArgs a) {
-    constexpr int CT = 128, PT = 128, FC = 2, FP = 2, NST = 4;
-    constexpr int STAGE_BYTES = (CT + PT) * RROWB;  // 16 KiB
-    constexpr int EP_STRIDE = CT * 2 + 16;
-    constexpr unsigned OOR = 0x80000000u;
-    typedef __attribute__((address_space(3))) void lds_void;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wc = wave >> 1, wp = wave & 1;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int ct = slot % a.n_ctiles, pt = xcd * a.pt_per_xcd + slot / a.n_ctiles;
-    if (pt >= a.n_ptiles) return;
-    const int cout0 = ct * CT, pix0 = pt * PT;
-    const int n_taps = a.kh * a.kw;
-    const int nk = a.Kpad / RB;
-
-    // staging: one DMA = 16 rows x 64 B; wave w issues row groups w and w+4 of each operand
-    const int lrow = lane >> 2;                      // row inside the 16-row group
-    const int lchunk = (lane & 3) ^ ((lrow >> 2) & 3);  // logical 16-B chunk this lane fetches (source-side swizzle)
-    int p_base[2];
-    unsigned p_taps[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = pix0 + 16 * (wave + 4 * i) + lrow;
-        p_base[i] = 0; p_taps[i] = 0u;
-        if (m < a.M) {
-            const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
-            const int ho = r / a.Wo, wo = r - ho * a.Wo;
-            const int hi0 = ho * a.stride - a.pad_top, wi0 = wo * a.stride - a.pad_left;
-            p_base[i] = (((n * a.H + hi0) * a.W + wi0) * a.Cin + lchunk * 8) * 2;
-            unsigned bits = 0u, bit = 1u;
-            for (int dy = 0; dy < a.kh; ++dy)
-                for (int dx = 0; dx < a.kw; ++dx, bit <<= 1)
-                    if ((unsigned)(hi0 + dy) < (unsigned)a.H && (unsigned)(wi0 + dx) < (unsigned)a.W) bits |= bit;
-            p_taps[i] = bits;
-        }
-    }
-    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
-    const int a_off0 = ((cout0 + 16 * wave + lrow) * a.Kpad + lchunk * 8) * 2;
-    int s_tap = 0, s_cc0 = 0, s_kh = 0, s_kw = 0;  // scalar K walk, 4 chunks (32 channels) per tile
-    auto dma_stage = [&](int kt, int buf) {
-        char *A = smem + buf * STAGE_BYTES, *B = A + CT * RROWB;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(A + 16 * (wave + 4 * i) * RROWB), 16,
-                                                     a_off0 + i * (64 * a.Kpad * 2), kt * (RB * 2), 0, 0);
-        const int soff = ((s_kh * a.W + s_kw) * a.Cin + s_cc0 * 8) * 2;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const unsigned voff = ((p_taps[i] >> s_tap) & 1u) ? (unsigned)(p_base[i] + soff) : OOR;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(B + 16 * (wave + 4 * i) * RROWB), 16, (int)voff, 0, 0, 0);
-        }
-        if (a.korder == 0) {
-            s_cc0 += 4;
-            if (s_cc0 == a.cpt) {
-                s_cc0 = 0; ++s_tap;
-                if (++s_kw == a.kw) { s_kw = 0; ++s_kh; }
-            }
-        } else {  // (ci/64, tap, ci%64): two 32-channel tiles per (chunk, tap)
-            s_cc0 += 4;
-            if ((s_cc0 & 7) == 0) {
-                s_cc0 -= 8; ++s_tap;
-                if (++s_kw == a.kw) { s_kw = 0; ++s_kh; }
-                if (s_tap == n_taps) { s_tap = 0; s_kh = 0; s_kw = 0; s_cc0 += 8; }
-            }
-        }
-    };
-
-    f32x16 acc[FC][FP];
-#pragma unroll
-    for (int i = 0; i < FC; ++i)
-#pragma unroll
-        for (int j = 0; j < FP; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    const int lr = lane & 31, lh = lane >> 5;
-    int fa_off[2], fb_off[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        fa_off[kk] = rswz(wc * 64 + lr, kk * 2 + lh);
-        fb_off[kk] = CT * RROWB + rswz(wp * 64 + lr, kk * 2 + lh);
-    }
-
-    dma_stage(0, 0);
-    if (nk > 1) dma_stage(1, 1);
-    if (nk > 2) dma_stage(2, 2);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int ahead = min(2, nk - 1 - kt);  // stages issued after kt that may stay in flight (4 DMAs each)
-        if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // stage kt published; stage kt-1 released by every wave
-        if (kt + 3 < nk) dma_stage(kt + 3, (kt + 3) & (NST - 1));
-        const char *T = smem + (kt & (NST - 1)) * STAGE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[FC], fb[FP];
-#pragma unroll
-            for (int i = 0; i < FC; ++i) fa[i] = *reinterpret_cast<const bf16x8 *>(T + fa_off[kk] + i * 32 * RROWB);
-#pragma unroll
-            for (int j = 0; j < FP; ++j) fb[j] = *reinterpret_cast<const bf16x8 *>(T + fb_off[kk] + j * 32 * RROWB);
-#pragma unroll
-            for (int i = 0; i < FC; ++i)
-#pragma unroll
-                for (int j = 0; j < FP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-
-    // ---- epilogue (as conv_igemm_kernel)
-    constexpr int CPP = CT / 8, EP_ITERS = PT * CPP / 256;
-    auto out_offset = [&](int m, int c) -> size_t {
-        if (!a.adv) return (size_t)m * a.Cout + c;
-        const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
-        const int ho = r / a.Wo, wo = r - ho * a.Wo;
-        return (((size_t)n * a.Hf + ho * a.os + a.oy) * a.Wf + wo * a.os + a.ox) * a.Ctot + a.c_off + c;
-    };
-    u32x4 rres[EP_ITERS];
-    if (a.res) {
-#pragma unroll
-        for (int it = 0; it < EP_ITERS; ++it) {
-            const int e = tid + it * 256;
-            const int m = pix0 + e / CPP, c = cout0 + (e % CPP) * 8;
-            rres[it] = (u32x4){0u, 0u, 0u, 0u};
-            if (m < a.M && c < a.Cout) rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + out_offset(m, c)));
-        }
-    }
-    char *E = smem;
-#pragma unroll
-    for (int i = 0; i < FC; ++i) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c_local = (wc * FC + i) * 32 + 8 * g + 4 * lh;
-            const float4 bv = *reinterpret_cast<const float4 *>(a.bias + cout0 + c_local);
-#pragma unroll
-            for (int j = 0; j < FP; ++j) {
-                const int p_local = (wp * FP + j) * 32 + lr;
-                // packed adds (v_pk_add_f32), one-instruction bf16 pack, ReLU on the packed pair: 8 VALU per 4 values
-                f32x2 s01 = (f32x2){acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
-                f32x2 s23 = (f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
-                if (a.relu == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
-                uint2 pk;
-                pk.x = pk_bf16(s01.x, s01.y);
-                pk.y = pk_bf16(s23.x, s23.y);
-                if (a.relu == 1 && !a.res) { pk.x = pk_relu_bf16(pk.x); pk.y = pk_relu_bf16(pk.y); }
-                *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < EP_ITERS; ++it) {
-        const int e = tid + it * 256;
-        const int p_local = e / CPP, cc = e % CPP;
-        const int m = pix0 + p_local, c = cout0 + cc * 8;
-        if (m >= a.M || c >= a.Cout) continue;
-        u32x4 v = *reinterpret_cast<const u32x4 *>(E + p_local * EP_STRIDE + cc * 16);
-        const size_t off = out_offset(m, c);
-        if (a.res) {
-            const u32x4 rv = rres[it];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f32x2 sum = (f32x2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)} +
-                                  (f32x2){__uint_as_float(rv[k] << 16), __uint_as_float(rv[k] & 0xffff0000u)};
-                v[k] = pk_bf16(sum.x, sum.y);
-                if (a.relu == 1) v[k] = pk_relu_bf16(v[k]);
-            }
-        }
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + off));
-    }
-}
-
-static int launch_conv_ring32(ConvArgs &a, hipStream_t s) {
-    a.n_ctiles = (a.Cout + 127) / 128;
-    a.n_ptiles = (a.M + 127) / 128;
-    a.pt_per_xcd = (a.n_ptiles + 7) / 8;
-    const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
-    if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
-    const int lds = 4 * (128 + 128) * RROWB;  // 64 KiB: two workgroups per CU
-    hipLaunchKernelGGL(conv_ring32_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a);
-    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
-}
-
 
 template <int CT, bool ONE_HALO>
 static int launch_conv3x3_halo(ConvArgs &a, hipStream_t s) {
@@ -1500,7 +1171,7 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     a.res_up = at->res_upsample != 0 && params[3] != nullptr;
     // one LDS staging buffer by default: measured r01 (tools/conv_ab.py), 4 resident workgroups per CU with a serial
     // DMA -> MFMA loop beat 2 double-buffered ones on every benchmark layer (+8...43 %); variant 2 keeps the double buffer
-    a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 21 || at->variant == 25;
+    a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 25;
     a.stamp = at->variant == 25;
     if (at->variant == 25) variant_override = 2;
     if (at->variant == 20) variant_override = 2;
@@ -1539,7 +1210,10 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     a.cpt = a.Cin / 8;
     a.pointwise = a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad_top == 0 && a.pad_left == 0 && a.H == a.Ho && a.W == a.Wo;
     hipStream_t s = (hipStream_t)stream;
-    // variant: 0 = auto; 1 = register-staged 128x128; 2 = LDS-DMA 128x128; 3 = LDS-DMA 256(cout)x256(pix), 8 waves
+    // variant: 0 = auto (cost model below); 1 = register-staged 128x128; 2 = LDS-DMA 128x128 with two staging buffers;
+    // 5 = 128x128 on v_mfma 16x16x32; 11 = 128-cout halo kernel; 15 / 22 = ping-pong kernel (32x32x16 / 16x16x32 MFMA);
+    // 17-19 = ping-pong timing ablations / stamps (wrong results); 20 = LDS-DMA 128x128 with one staging buffer;
+    // 25 = 20 + stamps; 27 = 64-cout halo kernel
     int variant = variant_override >= 0 ? variant_override : at->variant;
     const long long x_bytes = (long long)a.N * a.H * a.W * a.Cin * 2, w_bytes = (long long)cout_pad * a.Kpad * 2;
     const bool dma_ok = x_bytes < 0x7fff0000LL && w_bytes < 0x7fff0000LL;  // 32-bit DMA offsets, out-of-range marker 2^31
@@ -1572,27 +1246,12 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     if (variant == 22 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0, 1>(a, s);  // same, 16x16x32 MFMA
     if (variant >= 17 && variant <= 19 && fast && dma_ok && a.Cout % 256 == 0)                       // timing ablations
         return variant == 17 ? launch_conv_pingpong<1>(a, s) : (variant == 18 ? launch_conv_pingpong<2>(a, s) : launch_conv_pingpong<4>(a, s));
-    if (variant == 12 && fast && ctile == 128 && !a.res_up) return launch_conv_ring32(a, s);
     if (ctile != 128) {
         if (variant == 1) return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 0>(a, s) : launch_conv<256, 1, 4, 1, 2, 0>(a, s);
         if (fast) return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 2>(a, s) : launch_conv<256, 1, 4, 1, 2, 2>(a, s);
         return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 1>(a, s) : launch_conv<256, 1, 4, 1, 2, 1>(a, s);
     }
-    const bool can256 = cout_pad % 256 == 0;
-    if (variant == 21 && fast) return launch_conv<256, 2, 2, 2, 1, 2>(a, s);  // 128(cout) x 64(pix), single buffer
-    if (variant == 13 && fast && ctile == 128) return launch_conv<256, 2, 2, 2, 2, 2, 3>(a, s);           // 128x128, interleaved DMA issue
-    if (variant == 14 && fast && ctile == 128 && can256) return launch_conv<512, 2, 4, 4, 2, 2, 3>(a, s);  // 256x256, interleaved
-    if (variant == 0) variant = 2;  // measured (tools/conv_ab.py, r01): the 128x128 LDS-DMA kernel at 2 workgroups/CU beats
-                                    // the 256x256 8-wave one on every benchmark layer with this one-barrier-per-tile loop
-    if (variant == 3 && !can256) variant = 2;
-    if (variant == 1) return launch_conv<256, 2, 2, 2, 2, 0>(a, s);
-    if (variant == 3) return fast ? launch_conv<512, 2, 4, 4, 2, 2>(a, s) : launch_conv<512, 2, 4, 4, 2, 1>(a, s);
-    if (variant == 4 && fast) return launch_conv<512, 2, 4, 2, 2, 2, 1>(a, s);  // 128(cout) x 256(pix), 3-stage ring
-    if (variant == 5 && fast) return launch_conv<256, 2, 2, 2, 2, 2, 0, 1>(a, s);  // 128x128, 16x16x32 MFMA
-    if (variant == 6 && fast) return launch_conv<256, 2, 2, 2, 2, 2, 0, 2>(a, s);  // timing ablation: staging only (wrong results)
-    if (variant == 7 && fast) return launch_conv<256, 2, 2, 2, 2, 2, 0, 3>(a, s);  // timing ablation: compute only (wrong results)
-    if (variant == 10 && fast) return launch_conv<512, 2, 2, 2, 2, 2, 2>(a, s);  // 128x128, 4 compute + 4 staging waves
-    if (variant == 8 && fast && can256) return launch_conv<512, 2, 4, 4, 2, 2, 0, 2>(a, s);  // 256x256 staging only
-    if (variant == 9 && fast && can256) return launch_conv<512, 2, 4, 4, 2, 2, 0, 3>(a, s);  // 256x256 compute only
+    if (variant == 1) return launch_conv<256, 2, 2, 2, 2, 0>(a, s);               // register-staged, 64-bit addressing
+    if (variant == 5 && fast) return launch_conv<256, 2, 2, 2, 2, 2, 1>(a, s);    // 128x128, 16x16x32 MFMA
     return fast ? launch_conv<256, 2, 2, 2, 2, 2>(a, s) : launch_conv<256, 2, 2, 2, 2, 1>(a, s);
 }

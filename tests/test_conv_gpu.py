@@ -36,7 +36,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 15, 16, 20, 22, 27])
+@pytest.mark.parametrize("variant", [0, 1, 2, 5, 11, 15, 16, 20, 22, 27])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_conv_vs_torch_fp32(case, variant):
     from minddet_amd import nn_ops
