@@ -136,7 +136,7 @@ typedef struct md_conv2d_attrs {
                                     5 128x128 on 16x16x32 MFMA, 11 / 27 halo-reuse kernel with 128- / 64-cout tiles,
                                     15 / 22 256x256 ping-pong kernel (32x32x16 / 16x16x32 MFMA); a variant whose
                                     preconditions do not hold falls back to the generic kernel.  17-19 and 25 are timing /
-                                    stamp diagnostics of tools/*.py and do NOT compute the convolution. */
+                                    stamp diagnostics (tools/pp_stamps.py, tools/igemm_stamps.py) and do NOT compute the convolution. */
     /* generalised addressing, used when adv != 0 (all zero = plain conv).  The op then computes, for
      * ho < sub_h, wo < sub_w:  y[n, ho*out_stride + out_off_y, wo*out_stride + out_off_x, c_off + c] =
      * act(bias[c] + sum x[n, ho*stride - pad_top + kh, wo*stride - pad_left + kw, ci] * w[c,kh,kw,ci]), c < cout.

@@ -120,7 +120,9 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 
 // MF 0: v_mfma_f32_32x32x16_bf16 (FC x FP tiles of 32x32 per wave); MF 1: v_mfma_f32_16x16x32_bf16 (2FC x 2FP
 // tiles of 16x16, K 32 per instruction): same LDS traffic and cycles per flop, but the chip holds a higher
 // clock on the 16x16 shape under load (MI355X_MICROARCH.md, DVFS give-back item 7).
-template <int NT, int WC, int WP, int FC, int FP, int MODE, int MF = 0>
+// GEN false: the plain instantiation (no sub-pixel / concat addressing, no upsampled residual, no SiLU): the division-heavy
+// address code and the SiLU path of the general epilogue are compiled out (they were 2/3 of the kernel's instructions).
+template <int NT, int WC, int WP, int FC, int FP, int MODE, int MF = 0, bool GEN = true>
 __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr bool GLDS = MODE != 0;
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
@@ -392,13 +394,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
     constexpr int CPP = CT / 8;                 // 16-B chunks per pixel row of the tile
     constexpr int EP_ITERS = PT * CPP / NT;     // chunks per thread
     auto out_offset = [&](int m, int c) -> size_t {
-        if (!a.adv) return (size_t)m * a.Cout + c;
+        if (!(GEN && a.adv)) return (size_t)m * a.Cout + c;
         const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
         const int ho = r / a.Wo, wo = r - ho * a.Wo;
         return (((size_t)n * a.Hf + ho * a.os + a.oy) * a.Wf + wo * a.os + a.ox) * a.Ctot + a.c_off + c;
     };
     auto res_offset = [&](int m, int c) -> size_t {
-        if (!a.res_up) return out_offset(m, c);
+        if (!(GEN && a.res_up)) return out_offset(m, c);
         const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
         const int ho = r / a.Wo, wo = r - ho * a.Wo;
         const int Hr = (a.Ho + 1) >> 1, Wr = (a.Wo + 1) >> 1;
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
                 float v0 = acc4[i][j][0] + bv.x, v1 = acc4[i][j][1] + bv.y, v2 = acc4[i][j][2] + bv.z, v3 = acc4[i][j][3] + bv.w;
                 if (a.relu == 1 && !a.res) {
                     v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                } else if (a.relu == 2) {
+                } else if (GEN && a.relu == 2) {
                     v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
                 }
                 uint2 pk;
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
                 // packed adds (v_pk_add_f32), one-instruction bf16 pack, ReLU on the packed pair: 8 VALU per 4 values
                 f32x2 s01 = (f32x2){acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
                 f32x2 s23 = (f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
-                if (a.relu == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
+                if (GEN && a.relu == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
                 uint2 pk;
                 pk.x = pk_bf16(s01.x, s01.y);
                 pk.y = pk_bf16(s23.x, s23.y);
@@ -500,6 +502,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
 
 template <int NT, int WC, int WP, int FC, int FP, int MODE, int MF = 0>
 static int launch_conv(ConvArgs &a, hipStream_t s) {
+    const bool plain = MODE == 2 && MF == 0 && !a.adv && !a.res_up && a.relu != 2;
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
     g_last_kernel = MODE == 1 ? MD_CONV_KERNEL_IGEMM_GENERIC_K : (CT == 128 && PT == 128 ? MD_CONV_KERNEL_IGEMM_128 :
                     (CT < 128 ? MD_CONV_KERNEL_IGEMM_SMALL_COUT : MD_CONV_KERNEL_OTHER));
@@ -516,7 +519,7 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
     a.pt_per_xcd = (a.n_ptiles + 7) / 8;
     const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
-    auto k = conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, MF>;
+    auto k = plain ? conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, MF, !(MODE == 2 && MF == 0)> : conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, MF, true>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return MD_ERR_HIP;
@@ -769,7 +772,7 @@ struct KWalk { int tap, kh, kw, cc0; };
 
 // MF 0: v_mfma_f32_32x32x16_bf16, MF 1: v_mfma_f32_16x16x32_bf16 (same LDS image, reads and cycles per flop; the chip holds a
 // different clock on the two shapes under load -- MI355X_MICROARCH.md DVFS item 7 -- so both are built and the faster kept).
-template <int ABL, int MF = 0>  // ABL 0: product; timing ablations (wrong results): 1 no in-loop staging, 2 no output stores, 4 stamps
+template <int ABL, int MF = 0, bool GEN = true>  // GEN as in conv_igemm_kernel; ABL 0: product; timing ablations (wrong results): 1 no in-loop staging, 2 no output stores, 4 stamps
 __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     constexpr int CT = 256, PT = 256, NT = 512;
     constexpr int EP_STRIDE = CT * 2 + 16;
@@ -786,6 +789,8 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     if (pt >= a.n_ptiles) return;
     const int cout0 = ct * CT, pix0 = pt * PT;
     const int n_taps = a.kh * a.kw, nk = a.Kpad / BK;
+    unsigned long long clk_start = 0;
+    if (ABL == 4) clk_start = __builtin_readcyclecounter();
     // bias: requested now, parked in LDS past the epilogue image after the prologue wait (see conv_igemm_kernel)
     const float bias_early = tid < CT ? a.bias[cout0 + tid] : 0.f;
     float *bias_lds = reinterpret_cast<float *>(smem + PT * EP_STRIDE);
@@ -1006,7 +1011,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
                 float v0 = acc4[i][j][0] + bv.x, v1 = acc4[i][j][1] + bv.y, v2 = acc4[i][j][2] + bv.z, v3 = acc4[i][j][3] + bv.w;
                 if (a.relu == 1 && !a.res) {
                     v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                } else if (a.relu == 2) {
+                } else if (GEN && a.relu == 2) {
                     v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
                 }
                 uint2 pk;
@@ -1028,7 +1033,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
                 // packed adds (v_pk_add_f32), one-instruction bf16 pack, ReLU on the packed pair: 8 VALU per 4 values
                 f32x2 s01 = (f32x2){acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
                 f32x2 s23 = (f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
-                if (a.relu == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
+                if (GEN && a.relu == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
                 uint2 pk;
                 pk.x = pk_bf16(s01.x, s01.y);
                 pk.y = pk_bf16(s23.x, s23.y);
@@ -1039,13 +1044,13 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     }
     __syncthreads();
     auto out_offset = [&](int m, int c) -> size_t {
-        if (!a.adv) return (size_t)m * a.Cout + c;
+        if (!(GEN && a.adv)) return (size_t)m * a.Cout + c;
         const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
         const int ho = r / a.Wo, wo = r - ho * a.Wo;
         return (((size_t)n * a.Hf + ho * a.os + a.oy) * a.Wf + wo * a.os + a.ox) * a.Ctot + a.c_off + c;
     };
     auto res_offset = [&](int m, int c) -> size_t {
-        if (!a.res_up) return out_offset(m, c);
+        if (!(GEN && a.res_up)) return out_offset(m, c);
         const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
         const int ho = r / a.Wo, wo = r - ho * a.Wo;
         const int Hr = (a.Ho + 1) >> 1, Wr = (a.Wo + 1) >> 1;
@@ -1081,12 +1086,15 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         if (ABL == 2 && v[0] != 0x12345u) continue;
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + out_offset(m, c)));
     }
-    if (ABL == 4 && blockIdx.x == 0) {  // diagnostic build only: the stamps overwrite the first output pixels
+    if (ABL == 4 && blockIdx.x == (gridDim.x / 2 & ~7u)) {  // diagnostic build only: a mid-grid workgroup's stamps overwrite the first output pixels
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long clk_end = __builtin_readcyclecounter();
         __syncthreads();
         if (lane == 0) {
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(a.y) + wave * 16;
             for (int i = 0; i < 11; ++i) dbg[i] = keep[i];
             dbg[11] = clk1 - clk0; dbg[12] = rt1 - rt0;
+            dbg[13] = clk0 - clk_start; dbg[14] = clk_end - clk1;  // prologue / epilogue cycles
         }
     }
 }
@@ -1100,9 +1108,11 @@ static int launch_conv_pingpong(ConvArgs &a, hipStream_t s) {
     const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
     const int lds = 256 * (256 * 2 + 16) + 256 * 4;  // 136,192 B: the epilogue image (>= the 128 KiB of staging buffers) + bias
-    if (hipFuncSetAttribute((const void *)conv_pingpong_kernel<ABL, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-        return MD_ERR_HIP;
-    hipLaunchKernelGGL((conv_pingpong_kernel<ABL, MF>), dim3((unsigned)blocks), dim3(512), lds, s, a);
+    constexpr bool HAS_PLAIN = (ABL == 0 || ABL == 4) && MF == 0;
+    const bool plain = HAS_PLAIN && !a.adv && !a.res_up && a.relu != 2;
+    auto k = plain ? conv_pingpong_kernel<ABL, MF, !HAS_PLAIN> : conv_pingpong_kernel<ABL, MF, true>;
+    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 

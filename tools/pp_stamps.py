@@ -21,7 +21,7 @@ raw = y.view(-1)[: 8 * 64].view(torch.int64).cpu().reshape(8, 16)
 st = raw[:, :11]
 nk = k * k * Cin // 64
 print(f"main loop: {int(raw[0, 11])} cycles = {int(raw[0, 11]) / nk:.0f} per K tile, in-kernel clock "
-      f"{float(raw[0, 11]) / float(raw[0, 12]) * 100:.0f} MHz")
+      f"{float(raw[0, 11]) / float(raw[0, 12]) * 100:.0f} MHz; prologue {int(raw[0, 13])} cycles, epilogue {int(raw[0, 14])} cycles")
 names = ["issue0", "wait0", "barA0", "mfma0", "barB0", "issue1", "wait1", "barA1", "mfma1", "barB1"]
 print("wave " + " ".join(f"{n:>7s}" for n in names) + "   total   start-offset")
 t0 = int(st[:, 0].min())
