@@ -67,6 +67,14 @@ def test_size_limits_and_bad_arguments_return_codes():
     with pytest.raises(_lib.MindDetHipError):
         _lib.call("NmsGpu", [torch.zeros((4, 7)), torch.zeros((1,)), torch.zeros((4,), dtype=torch.int64),
                              torch.zeros((1,), dtype=torch.int32)])  # host tensors are refused before the call
+    # md_stem_pool: the image must be a multiple of 16 x 64 and arrive in the 4-channel stem layout
+    ps = nn_ops.pack_stem(torch.randn((64, 3, 7, 7))).to(DEV)
+    with pytest.raises(_lib.MindDetHipError, match="rc=2"):
+        nn_ops.stem_pool(torch.zeros((1, 40 + 16, 64 + 16, 4), dtype=torch.bfloat16, device=DEV), ps)   # H % 16 != 0
+    with pytest.raises(_lib.MindDetHipError, match="rc=2"):
+        _lib.call("md_stem_pool", [torch.zeros((1, 48, 80, 8), dtype=torch.bfloat16, device=DEV), ps.w, ps.bias,
+                                   torch.zeros((1, 8, 16, 64), dtype=torch.bfloat16, device=DEV)])      # 8-channel input
+    assert nn_ops.stem_pool(torch.zeros((0, 32 + 16, 64 + 16, 4), dtype=torch.bfloat16, device=DEV), ps).shape == (0, 8, 16, 64)
 
 
 def test_caller_workspace_is_used():
