@@ -92,6 +92,19 @@ def main():
                         last_kernel()))
         return y
 
+    orig_conv2d_head = nn_ops.conv2d_head
+
+    def timed_conv2d_head(x, pc, pc2, variant=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig_conv2d_head(x, pc, pc2, variant=variant)
+        e1.record()
+        n, ho, wo, _ = y.shape
+        fl = 2.0 * n * ho * wo * (pc.cout * pc.cin_real * pc.kh * pc.kw + pc2.cout * pc2.cin_real)
+        byts = 2.0 * (x.numel() + y.numel() + pc.cout * pc.cin_real * pc.kh * pc.kw + pc2.cout * pc2.cin_real)
+        records.append((e0, e1, fl, tuple(x.shape), pc.cout, pc.kh, byts, last_kernel()))
+        return y
+
     def step():
         dets, count = model.forward(images)
         if use_dist:
@@ -103,6 +116,7 @@ def main():
     instrument = not args.no_roofline
     if instrument:
         nn_ops.conv2d = timed_conv2d
+        nn_ops.conv2d_head = timed_conv2d_head
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier(device_ids=[local_rank])
@@ -114,6 +128,7 @@ def main():
         dist.barrier(device_ids=[local_rank])
     dt = time.perf_counter() - t0
     nn_ops.conv2d = orig_conv2d
+    nn_ops.conv2d_head = orig_conv2d_head
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

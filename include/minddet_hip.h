@@ -164,6 +164,15 @@ int md_conv2d(MD_AOT_ARGS);
  * pads Cout up to a multiple of it.  Pure function, callable without a GPU. */
 int md_conv2d_cout_tile(int cout);
 
+/* Conv (Cout = 256) + bias + ReLU followed by a 1x1 conv with <= 16 output channels (the RPN head of the two-stage
+ * detectors: shared 3x3 conv -> [objectness | deltas]); where the 256x256 ping-pong kernel applies, the 256-channel
+ * intermediate never leaves the CU (second GEMM straight from the epilogue image), otherwise two launches through a
+ * temporary.  Absent from the reference (its Faster R-CNN is a README bullet): parity unpinned.
+ * in : x[N,H,W,Cin] bf16, w[256,Kpad] bf16, bias[256] f32, w2[32,256] bf16 (rows >= 16 ignored), bias2[32] f32
+ * out: y2[N,Ho,Wo,16] bf16 ; optional trailing workspace (N*Ho*Wo*512 bytes, used only by the two-launch path)
+ * extra: md_conv2d_attrs of the FIRST conv (relu must be 1, plain addressing). */
+int md_conv2d_head(MD_AOT_ARGS);
+
 /* Which kernel the dispatcher launched for the calling host thread's most recent md_conv2d (0 before any call, or when
  * the call returned without launching).  Diagnostic only: lets bench.py attribute per-launch HIP-event timings. */
 enum {

@@ -54,6 +54,9 @@ struct ConvArgs {
     int adv;                // 0: plain (off = m*Cout + c)
     int korder;             // 0: K = (tap, ci); 1: K = (ci/64, tap, ci%64)  (MODE 2 only)
     int single_buf;         // LDS-DMA K loop with ONE staging buffer (four resident workgroups per CU)
+    const uint16_t *w2;     // fused 1x1 head (conv_pingpong_kernel<.., HEAD>): [>=16][256] bf16, K = the conv's 256 output channels
+    const float *b2;        // [>=16] fp32
+    uint16_t *y2;           // [N,Ho,Wo,16] bf16 -- the ONLY tensor a HEAD launch writes
     int pointwise;          // 1x1 / stride 1 / pad 0 (input pixel index == output pixel index)
     int bias_lds_off;       // byte offset of the CT-float bias copy in LDS (past the staging buffers and the epilogue image)
     int stamp;              // diagnostic (variant 25): a mid-grid workgroup overwrites the first output bytes with s_memtime stamps
@@ -772,7 +775,7 @@ struct KWalk { int tap, kh, kw, cc0; };
 
 // MF 0: v_mfma_f32_32x32x16_bf16, MF 1: v_mfma_f32_16x16x32_bf16 (same LDS image, reads and cycles per flop; the chip holds a
 // different clock on the two shapes under load -- MI355X_MICROARCH.md DVFS item 7 -- so both are built and the faster kept).
-template <int ABL, int MF = 0, bool GEN = true>  // GEN as in conv_igemm_kernel; ABL 0: product; timing ablations (wrong results): 1 no in-loop staging, 2 no output stores, 4 stamps
+template <int ABL, int MF = 0, bool GEN = true, bool HEAD = false>  // GEN as in conv_igemm_kernel; HEAD: fused 1x1 head; ABL 0: product; timing ablations (wrong results): 1 no in-loop staging, 2 no output stores, 4 stamps
 __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     constexpr int CT = 256, PT = 256, NT = 512;
     constexpr int EP_STRIDE = CT * 2 + 16;
@@ -935,6 +938,14 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
                                                                             acc4[2 * (I0) + i][j], 0, 0, 0);         \
     }
 
+    // HEAD: the 16 x 256 head weights -> LDS (8 KiB above the bias copy), one 1-KiB DMA per wave; lane -> (row, physical
+    // 16-B chunk), logical chunk = physical ^ row so that the 16 rows of an A-fragment read fall on 16 different slots
+    constexpr int W2_OFF = PT * EP_STRIDE + CT * 4;
+    if constexpr (HEAD) {
+        __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2, 0, 16 * 256 * 2, 0x00020000);
+        const int i = wave * 64 + lane, row = i >> 5, phys = i & 31;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (lds_void *)(smem + W2_OFF + wave * 1024), 16, row * 512 + ((phys ^ row) & 31) * 16, 0, 0, 0);
+    }
     // ---- prologue: tile 0 and the A0/B0/B1 halves of tile 1 (seven half tiles)
     KWalk w0 = {0, 0, 0, 0}, w1 = w0;
     walk_next(w1);
@@ -1043,6 +1054,32 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         }
     }
     __syncthreads();
+    if constexpr (HEAD) {
+        // ---- fused head: y2[p][c2] = b2[c2] + sum_k W2[c2][k] * relu(conv)[p][k], K = 256 straight from the epilogue image.
+        // v_mfma_f32_16x16x32_bf16 with A = W2 (16 head channels), B = 16 pixels; each wave owns 32 pixels.
+        const int l16 = lane & 15, lq = lane >> 4;
+        f32x4 h[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+            const bf16x8 wa = *reinterpret_cast<const bf16x8 *>(smem + W2_OFF + l16 * 512 + (((k2 * 4 + lq) ^ l16) & 31) * 16);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const bf16x8 xb = *reinterpret_cast<const bf16x8 *>(E + (wave * 32 + f * 16 + l16) * EP_STRIDE + (k2 * 32 + lq * 8) * 2);
+                h[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, h[f], 0, 0, 0);
+            }
+        }
+        const float4 hb = *reinterpret_cast<const float4 *>(a.b2 + 4 * lq);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int m = pix0 + wave * 32 + f * 16 + l16;
+            if (m >= a.M) continue;
+            uint2 pk;
+            pk.x = pk_bf16(h[f][0] + hb.x, h[f][1] + hb.y);
+            pk.y = pk_bf16(h[f][2] + hb.z, h[f][3] + hb.w);
+            *reinterpret_cast<uint2 *>(a.y2 + (size_t)m * 16 + 4 * lq) = pk;
+        }
+        return;
+    }
     auto out_offset = [&](int m, int c) -> size_t {
         if (!(GEN && a.adv)) return (size_t)m * a.Cout + c;
         const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
@@ -1099,6 +1136,20 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     }
 }
 
+static int launch_conv_pingpong_head(ConvArgs &a, hipStream_t s) {
+    g_last_kernel = MD_CONV_KERNEL_PINGPONG;
+    a.n_ctiles = 1;
+    a.n_ptiles = (a.M + 255) / 256;
+    a.pt_per_xcd = (a.n_ptiles + 7) / 8;
+    const long long blocks = (long long)a.pt_per_xcd * 8;
+    if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
+    const int lds = 256 * (256 * 2 + 16) + 256 * 4 + 16 * 256 * 2;  // epilogue image + bias + head weights
+    auto k = conv_pingpong_kernel<0, 0, false, true>;
+    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
+}
+
 template <int ABL = 0, int MF = 0>
 static int launch_conv_pingpong(ConvArgs &a, hipStream_t s) {
     g_last_kernel = MD_CONV_KERNEL_PINGPONG;
@@ -1131,7 +1182,14 @@ extern "C" long long md_conv2d_set_chunk_limit(long long bytes) {
 
 extern "C" int md_conv2d_cout_tile(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 
-extern "C" int md_conv2d(MD_AOT_ARGS) {
+struct HeadArgs {
+    const uint16_t *w2;
+    const float *b2;
+    uint16_t *y2;
+};
+#define MD_ERR_UNSUPPORTED_INTERNAL 100  // conv2d_entry with a head on a layer the fused kernel does not take
+
+static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     if (nparam != 5) return MD_ERR_NPARAM;
     if (!params || !extra || !params[1] || !params[2]) return MD_ERR_ARG;  // x / y may be null for an empty batch
     if (!dtype_is(dtypes, 0, "bfloat16") || !dtype_is(dtypes, 1, "bfloat16") || !dtype_is(dtypes, 2, "float32") ||
@@ -1159,7 +1217,9 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
                 int64_t *sh2[5] = {sx, shapes[1], shapes[2], params[3] ? sr : shapes[3], sy};
                 void *p2[5] = {(char *)params[0] + n0 * x_img, params[1], params[2],
                                params[3] ? (void *)((char *)params[3] + n0 * r_img) : nullptr, (char *)params[4] + n0 * y_img};
-                const int rc = md_conv2d(nparam, p2, ndims, sh2, dtypes, stream, extra);
+                HeadArgs h2;
+                if (head) { h2 = *head; h2.y2 += n0 * shapes[4][1] * shapes[4][2] * 16; }
+                const int rc = conv2d_entry(nparam, p2, ndims, sh2, dtypes, stream, extra, head ? &h2 : nullptr);
                 if (rc != MD_OK) return rc;
             }
             return MD_OK;
@@ -1245,6 +1305,11 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     const double sb_last = (double)(sb_blocks % 1024) / 1024.0;
     const double t_sb = (double)(sb_blocks / 1024) * 4.0 + (sb_blocks % 1024 ? 1.5 + 2.5 * sb_last : 0.0);
     const bool pp_ok = fast && dma_ok && a.Cout % 256 == 0 && a.Kpad >= 1024 && pp_blocks >= 128 && t_pp <= t_sb;
+    if (head) {
+        if (!(fast && dma_ok && a.Cout == 256 && !a.adv && !a.res && a.relu == 1 && pp_blocks >= 64)) return MD_ERR_UNSUPPORTED_INTERNAL;
+        a.w2 = head->w2; a.b2 = head->b2; a.y2 = head->y2;
+        return launch_conv_pingpong_head(a, s);
+    }
     if (variant == 0 && pp_ok) return launch_conv_pingpong<0>(a, s);
     if (halo_ok && !a.res_up && variant == 11) return launch_conv3x3_halo<128, false>(a, s);  // superseded by the paths around it
     // 64-cout tiles of the halo kernel at four workgroups per CU (variant 27; auto for Cout <= 64)
@@ -1264,4 +1329,51 @@ extern "C" int md_conv2d(MD_AOT_ARGS) {
     if (variant == 1) return launch_conv<256, 2, 2, 2, 2, 0>(a, s);               // register-staged, 64-bit addressing
     if (variant == 5 && fast) return launch_conv<256, 2, 2, 2, 2, 2, 1>(a, s);    // 128x128, 16x16x32 MFMA
     return fast ? launch_conv<256, 2, 2, 2, 2, 2>(a, s) : launch_conv<256, 2, 2, 2, 2, 1>(a, s);
+}
+
+extern "C" int md_conv2d(MD_AOT_ARGS) { return conv2d_entry(nparam, params, ndims, shapes, dtypes, stream, extra, nullptr); }
+
+// conv (Cout = 256, ReLU) followed by a 1x1 head with <= 16 output channels, in one launch where the ping-pong kernel
+// applies (the 256-channel intermediate then never leaves the CU); otherwise the two convolutions run back to back
+// through a stream-ordered temporary (or the caller's workspace).  The RPN head of the two-stage detectors: 3x3 conv +
+// ReLU -> [objectness | deltas].
+extern "C" int md_conv2d_head(MD_AOT_ARGS) {
+    // in: x[N,H,W,Cin], w[256,Kpad], bias[256], w2[32,256] (rows >= c2 zero), bias2[32] ; out: y2[N,Ho,Wo,16] ; [workspace]
+    if (nparam != 6 && nparam != 7) return MD_ERR_NPARAM;
+    if (!params || !extra || !ndims || !shapes || !params[3] || !params[4]) return MD_ERR_ARG;
+    if (!dtype_is(dtypes, 3, "bfloat16") || !dtype_is(dtypes, 4, "float32") || !dtype_is(dtypes, 5, "bfloat16")) return MD_ERR_ARG;
+    if (ndims[0] != 4 || ndims[1] != 2 || ndims[3] != 2 || ndims[5] != 4) return MD_ERR_ARG;
+    if (shapes[1][0] != 256 || shapes[3][0] < 16 || shapes[3][1] != 256 || numel(ndims, shapes, 4) < 16 || shapes[5][3] != 16 ||
+        shapes[5][0] != shapes[0][0])
+        return MD_ERR_ARG;
+    const md_conv2d_attrs *at = (const md_conv2d_attrs *)extra;
+    if (at->adv || at->relu != 1 || at->res_upsample) return MD_ERR_ARG;
+    const int64_t N = shapes[5][0], Ho = shapes[5][1], Wo = shapes[5][2];
+    if (N * Ho * Wo == 0) return MD_OK;
+    if (!params[0] || !params[5]) return MD_ERR_ARG;
+    // the conv as md_conv2d sees it: residual NULL, output [N,Ho,Wo,256] (never written by the fused kernel)
+    int64_t sy[4] = {N, Ho, Wo, 256}, snull[1] = {0};
+    int nd5[5] = {ndims[0], ndims[1], ndims[2], 0, 4};
+    int64_t *sh5[5] = {shapes[0], shapes[1], shapes[2], snull, sy};
+    const char *dt5[5] = {dtypes[0], dtypes[1], dtypes[2], nullptr, "bfloat16"};
+    HeadArgs head = {(const uint16_t *)params[3], (const float *)params[4], (uint16_t *)params[5]};
+    void *p5[5] = {params[0], params[1], params[2], nullptr, params[5] /* placeholder, not written */};
+    int rc = conv2d_entry(5, p5, nd5, sh5, dt5, stream, extra, &head);
+    if (rc != MD_ERR_UNSUPPORTED_INTERNAL) return rc;
+    // two launches through a temporary [N,Ho,Wo,256]
+    Scratch tmp;
+    const size_t bytes = (size_t)(N * Ho * Wo) * 256 * 2;
+    rc = tmp.acquire(bytes, nparam, params, ndims, shapes, 6, (hipStream_t)stream);
+    if (rc != MD_OK) return rc;
+    p5[4] = tmp.ptr;
+    rc = conv2d_entry(5, p5, nd5, sh5, dt5, stream, extra, nullptr);
+    if (rc != MD_OK) return rc;
+    md_conv2d_attrs a1 = {};
+    a1.kh = a1.kw = 1; a1.stride = 1; a1.pad = 0; a1.relu = 0; a1.variant = at->variant < 15 ? at->variant : 0;
+    int64_t sw2[2] = {shapes[3][0], 256}, sb2[1] = {shapes[3][0]};
+    int nd1[5] = {4, 2, 1, 0, 4};
+    int64_t *sh1[5] = {sy, sw2, sb2, snull, shapes[5]};
+    const char *dt1[5] = {"bfloat16", "bfloat16", "float32", nullptr, "bfloat16"};
+    void *p1[5] = {tmp.ptr, params[3], params[4], nullptr, params[5]};
+    return conv2d_entry(5, p1, nd1, sh1, dt1, stream, &a1, nullptr);
 }

@@ -8,12 +8,16 @@ for the kernels.  Random init follows SURVEY 8(d): He-normal std = sqrt(2/(k*k*C
 (centernet/src/resnet.py:210-213), BN gamma=1, beta=0, mean~N(0,0.1), var~U(0.5,1.5).
 """
 import math
+import os
 
 import numpy as np
 import torch
 
 from . import det_ops, nn_ops
 from .registry import BACKBONES, DETECTORS, HEADS, NECKS, ROI_HEAD, build_backbone, build_head, build_neck, build_roi_head
+
+
+RPN_FUSED_HEAD = os.environ.get("MD_RPN_FUSED", "1") == "1"  # 0: two md_conv2d launches per level (A/B)
 
 
 class ParamInit:
@@ -251,7 +255,10 @@ class RPNHead:
         counts = torch.empty((L, B), dtype=torch.int32, device=dev)
         heads = []
         for l, f in enumerate(feats):
-            head = self.out(self.conv(f))                       # [B,H,W,16]
+            if RPN_FUSED_HEAD and self.conv.cout == 256 and self.out.packed.cout == 16 and self.conv.relu:
+                head = nn_ops.conv2d_head(f, self.conv.packed, self.out.packed)   # [B,H,W,16], one launch per level
+            else:
+                head = self.out(self.conv(f))
             heads.append(head)
             logits = nn_ops.slice_cast(head, 0, A)              # [B,H,W,A] fp32
             _, idx, cnt = det_ops.topk_segmented(logits, st["seg"][l], k, out_cnt=counts[l],

@@ -116,6 +116,21 @@ def conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0, res
     return out
 
 
+def conv2d_head(x, pc, pc2, variant=None):
+    """conv (256 output channels, ReLU) + 1x1 head with <= 16 output channels in one md_conv2d_head call: [N,H,W,Cin] ->
+    [N,Ho,Wo,16] bf16 (the RPN head).  Falls back to two md_conv2d launches inside the library where the fused kernel
+    does not apply."""
+    n, h, w, c = x.shape
+    if c != pc.cin or pc.cout != 256 or pc2.cin != 256 or pc2.cout != 16 or pc2.kh != 1 or pc2.stride != 1 or pc2.pad != 0:
+        raise _lib.MindDetHipError("conv2d_head: needs a 256-channel conv followed by a 1x1 conv with 16 (padded) output channels")
+    ho, wo = conv_out_hw(h, w, pc)
+    y2 = torch.empty((n, ho, wo, 16), dtype=torch.bfloat16, device=x.device)
+    attrs = _ConvAttrs(pc.kh, pc.kw, pc.stride, pc.pad, 1, int(CONV_VARIANT if variant is None else variant))
+    attrs.korder = getattr(pc, "korder", 0)
+    _lib.call("md_conv2d_head", [x, pc.w, pc.bias, pc2.w, pc2.bias, y2], extra=attrs)
+    return y2
+
+
 class PackedConvT:
     """A transposed conv as s*s sub-pixel convs on the MFMA kernel (one launch per output parity)."""
 

@@ -192,3 +192,29 @@ def test_conv_batch_chunking_is_bit_identical():
         fn(old)
     torch.cuda.synchronize()
     assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 96), (1, 13, 21), (3, 75, 91)])
+def test_conv2d_head_fused_vs_two_launches(shape):
+    """md_conv2d_head (3x3 conv 256 -> 256 + ReLU, then a 1x1 head with 15 (->16) channels): one fused launch where the
+    ping-pong kernel applies (first / third shape), two launches through a temporary otherwise (second shape); both must
+    agree with md_conv2d twice (same bf16 intermediate, fp32 accumulation in a different order) and with fp32 torch."""
+    from minddet_amd import nn_ops
+
+    n, h, w = shape
+    g = torch.Generator().manual_seed(31 + h)
+    w1 = torch.randn((256, 256, 3, 3), generator=g) * (2.0 / 2304) ** 0.5
+    b1 = torch.randn((256,), generator=g) * 0.1
+    w2 = torch.randn((15, 256, 1, 1), generator=g) * 0.05
+    b2 = torch.randn((15,), generator=g) * 0.1
+    pc = nn_ops.pack_conv(w1, bias=b1, stride=1, pad=1, relu=True).to(DEV)
+    pc2 = nn_ops.pack_conv(w2, bias=b2).to(DEV)
+    x = torch.randn((n, h, w, 256), generator=g).to(torch.bfloat16)
+    y = nn_ops.conv2d_head(x.to(DEV), pc, pc2).float().cpu()
+    y_two = nn_ops.conv2d(nn_ops.conv2d(x.to(DEV), pc), pc2).float().cpu()
+    mid = torch.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w1.to(torch.bfloat16).float(), b1, padding=1)).to(torch.bfloat16).float()
+    ref = F.conv2d(mid, w2.to(torch.bfloat16).float(), b2).permute(0, 2, 3, 1)
+    assert y.shape == (n, h, w, 16) and (y[..., 15] == 0).all()
+    rms = ref.pow(2).mean().sqrt().item()
+    assert ((y[..., :15] - ref).abs() <= 1.5e-2 * ref.abs() + 1.5e-2 * rms).all()
+    assert ((y - y_two).abs() <= 1.0e-2 * y_two.abs() + 1.0e-2 * rms).all()
