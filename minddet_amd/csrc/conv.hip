@@ -402,22 +402,32 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         const int ho = r / a.Wo, wo = r - ho * a.Wo;
         return (((size_t)n * a.Hf + ho * a.os + a.oy) * a.Wf + wo * a.os + a.ox) * a.Ctot + a.c_off + c;
     };
-    auto res_offset = [&](int m, int c) -> size_t {
-        if (!(GEN && a.res_up)) return out_offset(m, c);
-        const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
-        const int ho = r / a.Wo, wo = r - ho * a.Wo;
-        const int Hr = (a.Ho + 1) >> 1, Wr = (a.Wo + 1) >> 1;
-        return (((size_t)n * Hr + (ho >> 1)) * Wr + (wo >> 1)) * a.Cout + c;
-    };
     u32x4 rres[EP_ITERS];
-    if (a.res) {
+    if (GEN && a.res_up) {
+        // upsampled residual (FPN top-down add): (n, ho, wo) of the thread's first pixel by division, the following
+        // pixels (NT / CPP apart) by carry -- two integer divisions per thread instead of two per 16-B chunk
+        const int c = cout0 + (tid % CPP) * 8;
+        int m = pix0 + tid / CPP;
+        int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
+        int ho = r / a.Wo, wo = r - ho * a.Wo;
+        const int Hr = (a.Ho + 1) >> 1, Wr = (a.Wo + 1) >> 1;
+#pragma unroll
+        for (int it = 0; it < EP_ITERS; ++it) {
+            rres[it] = (u32x4){0u, 0u, 0u, 0u};
+            if (m < a.M && c < a.Cout)
+                rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(
+                    a.res + (((size_t)n * Hr + (ho >> 1)) * Wr + (wo >> 1)) * a.Cout + c));
+            m += NT / CPP; wo += NT / CPP;
+            while (wo >= a.Wo) { wo -= a.Wo; if (++ho == a.Ho) { ho = 0; ++n; } }
+        }
+    } else if (a.res) {
 #pragma unroll
         for (int it = 0; it < EP_ITERS; ++it) {
             const int e = tid + it * NT;
             const int p_local = e / CPP, cc = e % CPP;
             const int m = pix0 + p_local, c = cout0 + cc * 8;
             rres[it] = (u32x4){0u, 0u, 0u, 0u};
-            if (m < a.M && c < a.Cout) rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + res_offset(m, c)));
+            if (m < a.M && c < a.Cout) rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + out_offset(m, c)));
         }
     }
     // bias (+ReLU when no residual) -> bf16x4 -> LDS [pixel][cout] image
