@@ -200,6 +200,16 @@ typedef struct md_pool_attrs {
 } md_pool_attrs;
 /* in x[N,H,W,C] bf16 ; out y[N,Ho,Wo,C] bf16.  extra: md_pool_attrs (required). */
 int md_maxpool2d(MD_AOT_ARGS);
+/* Modulated deformable convolution (DCNv2), step 1: deformable im2col.  Replaces ops.deformable_conv2d as wrapped by
+ * ModulatedDeformConv2d (minddet/models/centernet/src/resnet.py:24-106; CenterNet neck, centernet_det.py:123-160):
+ * in  x[N,H,W,C] bf16 ; off[N,Ho,Wo,Coff >= 3*k*k] bf16 = the offset conv's output in the wrapper's own channel order
+ *     (tap t = ky*k + kx: channel 2t = dy, 2t+1 = dx; channel 2*k*k + t = mask logit)
+ * out cols[N,Ho,Wo,k*k*C] bf16, cols[.., t*C + c] = sigmoid(mask_t) * bilinear(x[.., c]; ho*s - p + ky + dy_t, wo*s - p + kx + dx_t),
+ *     zero outside the image.  extra: md_pool_attrs (k, stride, pad).
+ * Step 2 is md_conv2d with kh = kw = 1 on `cols` and the layer's [Cout][k*k*C] weights (K order (tap, channel) = the packed
+ * 3x3 layout).  The arithmetic of the MindSpore primitive is not in the reference: published DCNv2 definition, parity unpinned. */
+int md_deform_cols(MD_AOT_ARGS);
+
 /* The ResNet stem in one launch: conv 7x7 / s2 / p3 (3 -> 64) + folded BN + ReLU + zero-pad + MaxPool 3x3 / s2
  * (minddet/models/centernet/src/resnet.py:199-204 and :226-233; the stem of every ResNet graph of the reference).
  * in : x[N, H+16, W+16, 4] bf16 -- the image in the STEM LAYOUT: channels (c0, c1, c2, 0), a zero border of

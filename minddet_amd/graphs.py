@@ -428,25 +428,55 @@ class DeconvModule:
         return nn_ops.conv_transpose2d(x, self.packed, out=out, c_off=c_off)
 
 
+class DeformConvModule:
+    """ModulatedDeformConv2d (DCNv2) + BatchNorm2d + ReLU -- centernet/src/resnet.py:24-106, used by the CenterNet neck
+    (centernet_det.py:123-160): offset conv (3*k*k channels, has_bias) -> md_deform_cols -> 1x1 md_conv2d over the columns.
+    The reference zero-initialises the offset conv; here it gets a small random init so that random-weight runs and tests
+    exercise the sampling path."""
+
+    def __init__(self, init, cin, cout, k=3, stride=1, pad=1, bn=True, relu=True, bn_eps=1e-5, offset_std=0.02):
+        self.cin, self.cout, self.k, self.stride, self.pad, self.relu = cin, cout, k, stride, pad, relu
+        self.act = "relu" if relu else None
+        self.weight = init.conv(cout, cin, k, None)
+        self.bn = init.bn(cout, bn_eps) if bn else None
+        self.bias = None
+        self.offset_weight = init.conv(3 * k * k, cin, k, offset_std)
+        self.offset_bias = torch.from_numpy(init.rng.normal(0.0, 0.1, (3 * k * k,)).astype(np.float32))
+        self.packed = self.packed_offset = None
+
+    def to(self, device):
+        self.packed = nn_ops.pack_conv(self.weight, bn=self.bn, stride=self.stride, pad=self.pad, relu=self.act, korder=0).to(device)
+        self.packed_offset = nn_ops.pack_conv(self.offset_weight, bias=self.offset_bias, stride=self.stride, pad=self.pad,
+                                              relu=False).to(device)
+        return self
+
+    def __call__(self, x):
+        return nn_ops.deform_conv2d(x, self.packed_offset, self.packed)
+
+    def macs(self, ho, wo):
+        return ho * wo * (self.cout + 3 * self.k * self.k) * self.cin * self.k * self.k
+
+
 @DETECTORS.register_module
 class CenterNet:
     """centernet/src/centernet_det.py:79-174 (GatherDetectionFeatureCell) + :374-399 (CenterNetDetEval):
     ResNet-18 -> 3 x [3x3 conv + BN + ReLU, Conv2dTranspose 4x4 s2 p1 + BN + ReLU] (512->256->128->64)
     -> hm / wh / reg heads (3x3 conv 64 + ReLU, 1x1 conv; hm bias -2.19, :29-69) -> sigmoid+clip ->
     DetectionDecode (decode.py:123-196).
-    Deviation, as SURVEY 7.5 plans: the three ModulatedDeformConv2d 3x3 layers (DCNv2, resnet.py:24-106,
-    arithmetic inside un-vendored MindSpore) are plain 3x3 convs here.
+    The three ModulatedDeformConv2d 3x3 layers (DCNv2, resnet.py:24-106) run as DeformConvModule (published DCNv2
+    definition: the primitive's arithmetic is inside un-vendored MindSpore, parity unpinned); `dcn=False` substitutes plain
+    3x3 convs.
     The three heads are evaluated as one fused 3x3 conv (64 -> 3*head_conv) and one block-diagonal 1x1
     conv (same arithmetic per output: the off-block weights are exact zeros)."""
 
     def __init__(self, depth=18, num_classes=80, head_conv=64, K=100, base_width=64, seed=7, train_cfg=None,
-                 test_cfg=None):
+                 test_cfg=None, dcn=True):
         init = ParamInit(seed)
         self.backbone = ResNet(depth, base_width=base_width, init=init)
         cin = self.backbone.out_channels[-1]
         self.neck = []
         for cout in (base_width * 4, base_width * 2, base_width):
-            self.neck.append(ConvModule(init, cin, cout, 3, 1, 1))
+            self.neck.append(DeformConvModule(init, cin, cout, 3, 1, 1) if dcn else ConvModule(init, cin, cout, 3, 1, 1))
             self.neck.append(DeconvModule(init, cout, cout, 4, 2, 1))
             cin = cout
         self.num_classes, self.head_conv, self.K = num_classes, head_conv, K

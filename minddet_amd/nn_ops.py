@@ -296,3 +296,24 @@ def stem_pool(x4, ps):
     y = torch.empty((n, h // 4, w // 4, 64), dtype=torch.bfloat16, device=x4.device)
     _lib.call("md_stem_pool", [x4, ps.w, ps.bias, y])
     return y
+
+
+# ----------------------------------------------------------------------------- DCNv2 (csrc/dcn.hip)
+class _PoolAttrs3(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32), ("zero_pad", ctypes.c_int32)]
+
+
+def deform_conv2d(x, pc_offset, pc, relu=None):
+    """ModulatedDeformConv2d (centernet/src/resnet.py:24-106): offset conv (md_conv2d, 3*k*k channels) -> deformable
+    im2col (md_deform_cols) -> the main conv as a 1x1 GEMM over the k*k*C columns (md_conv2d).  `pc` is the layer's packed
+    k x k conv with K order (tap, channel) (pack_conv(..., korder=0))."""
+    n, h, w, c = x.shape
+    if getattr(pc, "korder", 0) != 0 or pc.kh != pc.kw or pc.cin != c:
+        raise _lib.MindDetHipError("deform_conv2d: the main conv must be packed with korder=0 for this input")
+    off = conv2d(x, pc_offset)                                   # [N,Ho,Wo,>=3*k*k]
+    ho, wo = off.shape[1], off.shape[2]
+    cols = torch.empty((n, ho, wo, pc.kh * pc.kw * c), dtype=torch.bfloat16, device=x.device)
+    _lib.call("md_deform_cols", [x, off, cols], extra=_PoolAttrs3(pc.kh, pc.stride, pc.pad, 0))
+    pw = PackedConv(pc.w, pc.bias, pc.kh * pc.kw * c, pc.cout, 1, 1, 1, 0, pc.relu)
+    pw.cin_real, pw.korder = pc.kh * pc.kw * c, 0
+    return conv2d(cols, pw, relu=relu)

@@ -50,6 +50,44 @@ def conv_module(m, x, residual=None, quant=False):
     return _q(y, quant)
 
 
+def deform_conv_module(m, x, quant=False):
+    """DCNv2 as wrapped by centernet/src/resnet.py:24-106 (published definition; the MindSpore primitive's arithmetic is not
+    in the reference: parity unpinned).  Mirrors the device data path: offset conv -> bf16, modulated bilinear columns ->
+    bf16, fp32 GEMM + folded-BN bias -> ReLU -> bf16."""
+    n, c, h, w = x.shape
+    k, s, p = m.k, m.stride, m.pad
+    off = _q(F.conv2d(x, _q(m.offset_weight.float(), quant), m.offset_bias.float(), stride=s, padding=p), quant)
+    ho, wo = off.shape[2], off.shape[3]
+    wf, bf = fold(m)
+    wf = _q(wf, quant)
+    ys = torch.arange(ho, dtype=torch.float32).view(1, ho, 1) * s - p
+    xs = torch.arange(wo, dtype=torch.float32).view(1, 1, wo) * s - p
+    out = torch.zeros((n, wf.shape[0], ho, wo))
+    xp = x.reshape(n, c, h * w)
+    for t in range(k * k):
+        ky, kx = t // k, t % k
+        py = ys + ky + off[:, 2 * t]
+        px = xs + kx + off[:, 2 * t + 1]
+        mask = torch.sigmoid(off[:, 2 * k * k + t])
+        inside = (py > -1) & (py < h) & (px > -1) & (px < w)
+        y0, x0 = torch.floor(py), torch.floor(px)
+        ly, lx = py - y0, px - x0
+        val = torch.zeros((n, c, ho, wo))
+        for dy_, dx_ in ((0, 0), (0, 1), (1, 0), (1, 1)):
+            yy, xx = (y0 + dy_).long(), (x0 + dx_).long()
+            wgt = (ly if dy_ else 1 - ly) * (lx if dx_ else 1 - lx)
+            ok = inside & (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+            idx = (yy.clamp(0, h - 1) * w + xx.clamp(0, w - 1)).view(n, 1, ho * wo).expand(n, c, ho * wo)
+            g = torch.gather(xp, 2, idx).view(n, c, ho, wo)
+            val = val + (wgt * ok).unsqueeze(1) * g
+        col = _q(val * mask.unsqueeze(1), quant)
+        out = out + torch.einsum("oc,nchw->nohw", wf[:, :, ky, kx], col)
+    out = out + bf.view(1, -1, 1, 1)
+    if m.relu:
+        out = torch.relu(out)
+    return _q(out, quant)
+
+
 def resnet_forward(bb, x, quant=False):
     x = conv_module(bb.conv1, x, quant=quant)
     x = F.max_pool2d(F.pad(x, (1, 1, 1, 1), value=0.0), 3, 2)  # resnet.py:199-204
@@ -237,7 +275,12 @@ def centernet_features(model, x, quant=False):
     """centernet/src/centernet_det.py:162-174 with the UNFUSED heads (three 3x3 + three 1x1 convs)."""
     f = resnet_forward(model.backbone, x, quant)[-1]
     for m in model.neck:
-        f = deconv_module(m, f, quant) if hasattr(m, "weight_t") else conv_module(m, f, quant=quant)
+        if hasattr(m, "weight_t"):
+            f = deconv_module(m, f, quant)
+        elif hasattr(m, "offset_weight"):
+            f = deform_conv_module(m, f, quant)
+        else:
+            f = conv_module(m, f, quant=quant)
     out = {}
     for name, (c1, c2) in model.heads.items():
         out[name] = conv_module(c2, conv_module(c1, f, quant=quant), quant=quant)
