@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "faster_rcnn", "faster_rcnn_r50_fpn.py"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--from-uint8", action="store_true",
+                    help="start every step from a resident uint8 batch: md_image_preprocess (warp + normalise + layout) is timed too")
     ap.add_argument("--dump-convs", default=None, help="write per-launch conv timings (json) to this path")
     args = ap.parse_args()
 
@@ -105,8 +107,18 @@ def main():
         records.append((e0, e1, fl, tuple(x.shape), pc.cout, pc.kh, byts, last_kernel()))
         return y
 
+    images_u8 = pre_mat = None
+    if args.from_uint8:
+        g_u8 = torch.Generator(device="cpu").manual_seed(20240317 + rank)
+        images_u8 = torch.randint(0, 256, (B, H, W, 3), generator=g_u8, dtype=torch.uint8).to(dev)
+        pre_mat = torch.tensor([1.0, 0, 0, 0, 1.0, 0], dtype=torch.float32, device=dev).repeat(B, 1).contiguous()
+
     def step():
-        dets, count = model.forward(images)
+        x = images
+        if images_u8 is not None:
+            x = nn_ops.image_preprocess(images_u8, pre_mat, (0.408, 0.447, 0.470), (0.289, 0.274, 0.278), (H, W),
+                                        stem_layout=images.shape[3] == 4)
+        dets, count = model.forward(x)
         if use_dist:
             return gather_detections(dets, count, force=True)
         return dets, count

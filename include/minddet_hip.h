@@ -200,6 +200,19 @@ typedef struct md_pool_attrs {
 } md_pool_attrs;
 /* in x[N,H,W,C] bf16 ; out y[N,Ho,Wo,C] bf16.  extra: md_pool_attrs (required). */
 int md_maxpool2d(MD_AOT_ARGS);
+/* Image pre-processing on the device: bilinear affine warp with constant-0 border + normalisation +
+ * layout.  Replaces cv2.resize + cv2.warpAffine(INTER_LINEAR) + (img / 255 - mean) / std of
+ * minddet/models/centernet/src/dataset.py:223-256 and the ImagePreProcess cell of centernet_det.py:240-262.
+ * in : img[N,Hs,Ws,3] uint8 ; mat[N,6] f32 = per image the 2x3 matrix mapping OUTPUT pixel (x, y) to SOURCE pixel
+ *      (sx = m0 x + m1 y + m2, sy = m3 x + m4 y + m5) ; norm[6] f32 = mean[3], std[3] of the 0..1 image
+ * out: y[N, pad_lo + out_h + pad_hi, pad_lo + out_w + pad_hi, C] bf16, C = 4 (stem layout: pad_lo 7, pad_hi 9) or 8
+ *      (pad 0); channels 3.. and the border are zero.
+ * fp32 interpolation (cv2's 1/32-pixel fixed point is not reproduced; cv2 is absent here: parity unpinned). */
+typedef struct md_preprocess_attrs {
+    int32_t out_h, out_w, pad_lo, pad_hi;
+} md_preprocess_attrs;
+int md_image_preprocess(MD_AOT_ARGS);
+
 /* Modulated deformable convolution (DCNv2), step 1: deformable im2col.  Replaces ops.deformable_conv2d as wrapped by
  * ModulatedDeformConv2d (minddet/models/centernet/src/resnet.py:24-106; CenterNet neck, centernet_det.py:123-160):
  * in  x[N,H,W,C] bf16 ; off[N,Ho,Wo,Coff >= 3*k*k] bf16 = the offset conv's output in the wrapper's own channel order

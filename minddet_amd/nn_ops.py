@@ -317,3 +317,21 @@ def deform_conv2d(x, pc_offset, pc, relu=None):
     pw = PackedConv(pc.w, pc.bias, pc.kh * pc.kw * c, pc.cout, 1, 1, 1, 0, pc.relu)
     pw.cin_real, pw.korder = pc.kh * pc.kw * c, 0
     return conv2d(cols, pw, relu=relu)
+
+
+# ----------------------------------------------------------------------------- image pre-processing (csrc/preproc.hip)
+class _PreAttrs(ctypes.Structure):
+    _fields_ = [("out_h", ctypes.c_int32), ("out_w", ctypes.c_int32), ("pad_lo", ctypes.c_int32), ("pad_hi", ctypes.c_int32)]
+
+
+def image_preprocess(img_u8, mat, mean, std, out_hw, stem_layout=True):
+    """uint8 [N,Hs,Ws,3] device images -> normalised bf16 network input, warped by `mat` [N,6] (output pixel -> source pixel;
+    e.g. the inverse of get_affine_transform(c, s, 0, (out_w, out_h)) of centernet/src/image.py:25-57).  stem_layout: the
+    zero-bordered 4-channel layout md_stem_pool consumes, else [N,out_h,out_w,8]."""
+    n = img_u8.shape[0]
+    ho, wo = out_hw
+    lo, hi, c = (STEM_PAD_LO, STEM_PAD_HI, 4) if stem_layout else (0, 0, 8)
+    out = torch.empty((n, ho + lo + hi, wo + lo + hi, c), dtype=torch.bfloat16, device=img_u8.device)
+    norm = torch.tensor(list(mean) + list(std), dtype=torch.float32, device=img_u8.device)
+    _lib.call("md_image_preprocess", [img_u8, mat, norm, out], extra=_PreAttrs(ho, wo, lo, hi))
+    return out

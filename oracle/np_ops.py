@@ -533,3 +533,32 @@ def centerpoint_decode(head, off, ncls, cfg):
     flipped[..., -1] = -flipped[..., -1] - np.float32(np.pi / 2)
     nms_boxes = flipped[..., [0, 1, 2, 4, 3, 5, -1]]
     return scores, labels, boxes, nms_boxes, mask
+
+
+def image_preprocess(img_u8, mat, mean, std, out_hw):
+    """Restatement of md_image_preprocess: bilinear affine warp (constant-0 border) + (v / 255 - mean) / std, fp32.
+    Semantics of cv2.warpAffine(..., flags=INTER_LINEAR) as called at centernet/src/dataset.py:244-247 with the matrix given in
+    the output->source direction, but interpolating in floating point (cv2 uses 1/32-pixel fixed point; cv2 is absent
+    here: parity unpinned).  img_u8 [N,Hs,Ws,3], mat [N,6] -> [N,Ho,Wo,3] float32."""
+    n, hs, ws, _ = img_u8.shape
+    ho, wo = out_hw
+    out = np.zeros((n, ho, wo, 3), np.float32)
+    ys, xs = np.meshgrid(np.arange(ho, dtype=np.float32), np.arange(wo, dtype=np.float32), indexing="ij")
+    mean = np.asarray(mean, np.float32)
+    std = np.asarray(std, np.float32)
+    for b in range(n):
+        m = mat[b].astype(np.float32)
+        sx = m[0] * xs + m[1] * ys + m[2]
+        sy = m[3] * xs + m[4] * ys + m[5]
+        x0, y0 = np.floor(sx), np.floor(sy)
+        lx, ly = sx - x0, sy - y0
+        acc = np.zeros((ho, wo, 3), np.float32)
+        for q in range(4):
+            yy = (y0 + (q >> 1)).astype(np.int64)
+            xx = (x0 + (q & 1)).astype(np.int64)
+            w = ((ly if q >> 1 else 1 - ly) * (lx if q & 1 else 1 - lx)).astype(np.float32)
+            ok = (yy >= 0) & (yy < hs) & (xx >= 0) & (xx < ws)
+            px = img_u8[b, yy.clip(0, hs - 1), xx.clip(0, ws - 1)].astype(np.float32)
+            acc += (w * ok)[..., None] * px
+        out[b] = (acc * np.float32(1.0 / 255.0) - mean) / std
+    return out
