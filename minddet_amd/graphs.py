@@ -445,7 +445,8 @@ class DeformConvModule:
         self.packed = self.packed_offset = None
 
     def to(self, device):
-        self.packed = nn_ops.pack_conv(self.weight, bn=self.bn, stride=self.stride, pad=self.pad, relu=self.act, korder=0).to(device)
+        self.packed = nn_ops.pack_conv(self.weight, bias=self.bias, bn=self.bn, stride=self.stride, pad=self.pad, relu=self.act,
+                                       korder=0).to(device)
         self.packed_offset = nn_ops.pack_conv(self.offset_weight, bias=self.offset_bias, stride=self.stride, pad=self.pad,
                                               relu=False).to(device)
         return self
@@ -490,10 +491,16 @@ class CenterNet:
             self.heads[name] = (c1, c2)
         # fused forms
         self.head1 = ConvModule(init, cin, 3 * hc, 3, 1, 1, bn=False, relu=True, bias=True)
-        self.head1.weight = torch.cat([self.heads[n][0].weight for n in ("hm", "wh", "reg")], 0)
-        self.head1.bias = torch.cat([self.heads[n][0].bias for n in ("hm", "wh", "reg")], 0)
         self.n_out = num_classes + 4
         self.head2 = ConvModule(init, 3 * hc, self.n_out, 1, bn=False, relu=False, bias=True)
+        self.fuse_heads()
+        self.decode = det_ops.DetectionDecode(reg_offset=True, K=K)
+
+    def fuse_heads(self):
+        """(Re)build the fused head convs from self.heads -- call after the per-head weights change (weights.py)."""
+        hc = self.head_conv
+        self.head1.weight = torch.cat([self.heads[n][0].weight for n in ("hm", "wh", "reg")], 0)
+        self.head1.bias = torch.cat([self.heads[n][0].bias for n in ("hm", "wh", "reg")], 0)
         w2 = torch.zeros((self.n_out, 3 * hc, 1, 1))
         b2 = torch.zeros((self.n_out,))
         o = 0
@@ -503,7 +510,6 @@ class CenterNet:
             b2[o:o + c2.cout] = c2.bias
             o += c2.cout
         self.head2.weight, self.head2.bias = w2, b2
-        self.decode = det_ops.DetectionDecode(reg_offset=True, K=K)
 
     def conv_modules(self):
         return self.backbone.modules() + self.neck + [self.head1, self.head2]
