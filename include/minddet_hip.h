@@ -200,6 +200,17 @@ typedef struct md_pool_attrs {
 } md_pool_attrs;
 /* in x[N,H,W,C] bf16 ; out y[N,Ho,Wo,C] bf16.  extra: md_pool_attrs (required). */
 int md_maxpool2d(MD_AOT_ARGS);
+/* Anchor target assignment on the device.  Replaces create_target_np
+ * (minddet/models/pointpillars/src/core/target_assigner.py:29-166) as TargetAssigner.assign drives it (:196-224) with
+ * positive_fraction None: similarity = iou_jit(rbbox2d_to_near_bbox(boxes[:, [0,1,3,4,6]]), eps 0)
+ * (region_similarity.py:46-59), encoding = second_box_encode (box_np_ops.py:8-37).
+ * in : anchors[A,7] f32, gt_boxes[G,7] f32, gt_classes[G] i32 (>= 1), matched_thr[A] f32, unmatched_thr[A] f32,
+ *      anchors_mask[A] u8 or NULL (NULL = all inside)
+ * out: labels[A] i32 (-1 ignore / outside the mask, 0 background, class), bbox_targets[A,7] f32,
+ *      bbox_outside_weights[A] f32 (1 on foreground), gt_ids[A] i32 (matched ground truth, -1 elsewhere)
+ * optional trailing workspace (4*G bytes).  G <= 1024.  labels / gt_ids bit-exact vs the reference; log() targets <= 4 ulp. */
+int md_assign_targets(MD_AOT_ARGS);
+
 /* Image pre-processing on the device: bilinear affine warp with constant-0 border + normalisation +
  * layout.  Replaces cv2.resize + cv2.warpAffine(INTER_LINEAR) + (img / 255 - mean) / std of
  * minddet/models/centernet/src/dataset.py:223-256 and the ImagePreProcess cell of centernet_det.py:240-262.

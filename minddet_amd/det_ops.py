@@ -670,3 +670,26 @@ def yolo_decode(head, boxes, scores, labels, num_classes, num_anchors, stride, a
         at.anchors[i] = float(v)
     at.conf_thres, at.out_offset, at.out_total = float(conf_thres), int(out_offset), int(out_total)
     _lib.call("md_yolo_decode", [head, boxes, scores, labels], extra=at)
+
+
+def assign_targets(anchors, gt_boxes, gt_classes, matched_thr, unmatched_thr, anchors_mask=None):
+    """create_target_np (pointpillars/src/core/target_assigner.py:29-166; TargetAssigner.assign :196-224) on the device:
+    -> (labels [A] i32, bbox_targets [A,7] f32, bbox_outside_weights [A] f32, gt_ids [A] i32).  Thresholds: float or [A]."""
+    a = _f32c(anchors).reshape(-1, 7)
+    dev, A = a.device, a.shape[0]
+    g = _f32c(gt_boxes).reshape(-1, 7)
+    G = g.shape[0]
+    cls = (torch.ones((G,), dtype=torch.int32, device=dev) if gt_classes is None
+           else gt_classes.to(device=dev, dtype=torch.int32).contiguous())
+
+    def thr(v):
+        return (torch.full((A,), float(v), dtype=torch.float32, device=dev) if not torch.is_tensor(v) else _f32c(v).reshape(-1))
+
+    mt, ut = thr(matched_thr), thr(unmatched_thr)
+    mask = None if anchors_mask is None else anchors_mask.to(device=dev, dtype=torch.uint8).contiguous()
+    labels = torch.empty((A,), dtype=torch.int32, device=dev)
+    targets = torch.empty((A, 7), dtype=torch.float32, device=dev)
+    weights = torch.empty((A,), dtype=torch.float32, device=dev)
+    gt_ids = torch.empty((A,), dtype=torch.int32, device=dev)
+    _lib.call("md_assign_targets", [a, g if G else None, cls if G else None, mt, ut, mask, labels, targets, weights, gt_ids])
+    return labels, targets, weights, gt_ids

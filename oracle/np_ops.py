@@ -562,3 +562,43 @@ def image_preprocess(img_u8, mat, mean, std, out_hw):
             acc += (w * ok)[..., None] * px
         out[b] = (acc * np.float32(1.0 / 255.0) - mean) / std
     return out
+
+
+# ----------------------------------------------------------------------------- target assignment
+def create_target(anchors, gt_boxes, gt_classes, matched_thr, unmatched_thr, anchors_mask=None):
+    """Restatement of create_target_np (PP/src/core/target_assigner.py:29-166) as TargetAssigner.assign calls it (:196-224)
+    with positive_fraction None: similarity = iou_jit(rbbox2d_to_near_bbox(.), eps 0) (region_similarity.py:46-59), encoding =
+    second_box_encode.  matched_thr / unmatched_thr: [A] float32.  Returns labels [A] int32 (-1 ignore / 0 background /
+    class), bbox_targets [A,7] float32, bbox_outside_weights [A] float32, gt_ids [A] int32 (-1 where not foreground)."""
+    A = anchors.shape[0]
+    labels = np.full((A,), -1, np.int32)
+    targets = np.zeros((A, 7), np.float32)
+    weights = np.zeros((A,), np.float32)
+    gt_ids = np.full((A,), -1, np.int32)
+    inside = np.arange(A) if anchors_mask is None or len(anchors_mask) == 0 else np.where(anchors_mask)[0]
+    a = anchors[inside]
+    lab = np.full((len(inside),), -1, np.int32)
+    if gt_boxes.shape[0] > 0 and len(inside) > 0:
+        ov = iou_jit(rbbox2d_to_near_bbox(a[:, [0, 1, 3, 4, 6]]), rbbox2d_to_near_bbox(gt_boxes[:, [0, 1, 3, 4, 6]]), eps=0.0)
+        arg = ov.argmax(axis=1)                      # first maximum, as numpy
+        amax = ov[np.arange(len(inside)), arg]
+        gmax = ov.max(axis=0).copy()
+        gmax[gmax == 0] = -1                         # a ground truth nothing overlaps forces no anchor
+        forced = (ov == gmax[None, :]).any(axis=1)
+        pos = amax >= matched_thr[inside]
+        fg = forced | pos
+        lab[fg] = gt_classes[arg[fg]]
+        bg = (amax < unmatched_thr[inside]) & ~forced   # labels[bg] = 0 first, then the forced anchors are re-labelled
+        lab[bg] = 0
+        fgi = np.where(lab > 0)[0]
+        t = np.zeros((len(inside), 7), np.float32)
+        t[fgi] = second_box_encode(gt_boxes[arg[fgi]], a[fgi])
+        targets[inside] = t
+        g = np.full((len(inside),), -1, np.int32)
+        g[fgi] = arg[fgi]
+        gt_ids[inside] = g
+    else:
+        lab[:] = 0
+    labels[inside] = lab
+    weights[inside] = (lab > 0).astype(np.float32)
+    return labels, targets, weights, gt_ids
