@@ -70,7 +70,7 @@ def main():
     H, W = cfg.data.input_hw
     B = args.batch
     images = synthetic_images(B, H, W, seed=20240317 + rank, device=dev)
-    if type(model).__name__ == "FasterRCNN" and nn_ops.stem_layout_ok(H, W) and os.environ.get("MD_STEM_LAYOUT", "1") == "1":
+    if type(model).__name__ in ("FasterRCNN", "MaskRCNN") and nn_ops.stem_layout_ok(H, W) and os.environ.get("MD_STEM_LAYOUT", "1") == "1":
         # the batch is resident in HBM in the model's input layout before the timed region starts: zero-bordered
         # 4-channel NHWC (md_stem_pool); MD_STEM_LAYOUT=0 keeps the 8-channel layout + two-launch stem for A/B
         images = nn_ops.to_stem_layout(images)
@@ -118,7 +118,8 @@ def main():
         if images_u8 is not None:
             x = nn_ops.image_preprocess(images_u8, pre_mat, (0.408, 0.447, 0.470), (0.289, 0.274, 0.278), (H, W),
                                         stem_layout=images.shape[3] == 4)
-        dets, count = model.forward(x)
+        out = model.forward(x)
+        dets, count = out[0], out[1]   # Mask R-CNN also returns masks [B,max_det,28,28]; they stay on their shard
         if use_dist:
             return gather_detections(dets, count, force=True)
         return dets, count

@@ -1,0 +1,20 @@
+# Mask R-CNN ResNet-101 FPN, inference (BASELINE.json configs[4]: "mask head + RoIAlign, heaviest det-ops path");
+# python-file config in the reference's Config.fromfile style.  The architecture is absent from the reference
+# (README bullet): standard public definition, parity unpinned.
+num_classes = 80
+model = dict(
+    type="MaskRCNN",
+    backbone=dict(type="ResNet", depth=101),
+    neck=dict(type="FPN", out_channels=256, num_outs=5),
+    rpn_head=dict(type="RPNHead", in_channels=256, feat_channels=256, strides=(4, 8, 16, 32, 64), scale=8.0,
+                  ratios=(0.5, 1.0, 2.0), nms_pre=1000, max_per_img=1000, nms_thr=0.7),
+    roi_head=dict(type="StandardRoIHead", in_channels=256, fc_channels=1024, num_classes=num_classes, roi_size=7,
+                  sampling_ratio=2, featmap_strides=(4, 8, 16, 32), score_thr=0.05, nms_thr=0.5, max_per_img=100,
+                  nms_pre=2048),
+    mask_head=dict(type="FCNMaskHead", in_channels=256, conv_channels=256, num_convs=4, num_classes=num_classes,
+                   roi_size=14, sampling_ratio=2, featmap_strides=(4, 8, 16, 32)),
+)
+train_cfg = None
+test_cfg = dict(max_per_img=100)
+data = dict(img_scale=(1333, 800), pad_divisor=32, input_hw=(800, 1344),
+            mean=[0.408, 0.447, 0.470], std=[0.289, 0.274, 0.278])

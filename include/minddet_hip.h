@@ -200,6 +200,11 @@ typedef struct md_pool_attrs {
 } md_pool_attrs;
 /* in x[N,H,W,C] bf16 ; out y[N,Ho,Wo,C] bf16.  extra: md_pool_attrs (required). */
 int md_maxpool2d(MD_AOT_ARGS);
+/* Mask R-CNN: per-detection class channel of the mask head + sigmoid (absent from the reference: standard head, parity
+ * unpinned).  in logits[R,S,S,Cpad] bf16, dets[R,6] f32 (x1,y1,x2,y2,score,label) ; out masks[R,S,S] f32 (zeros for empty
+ * detection slots).  extra: int32 num_classes. */
+int md_mask_select(MD_AOT_ARGS);
+
 /* Anchor target assignment on the device.  Replaces create_target_np
  * (minddet/models/pointpillars/src/core/target_assigner.py:29-166) as TargetAssigner.assign drives it (:196-224) with
  * positive_fraction None: similarity = iou_jit(rbbox2d_to_near_bbox(boxes[:, [0,1,3,4,6]]), eps 0)

@@ -308,3 +308,43 @@ extern "C" int md_pack_detections(MD_AOT_ARGS) {
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }
+
+// ------------------------------------------------------------------------------------------ Mask R-CNN mask select
+// logits [R,S,S,Cpad] bf16 (per-class mask logits), dets [R,6] f32 (x1,y1,x2,y2,score,label) -> masks [R,S,S] f32 =
+// sigmoid(logit of the detection's own class); rows of empty detection slots (score 0) give zeros.  Absent from the
+// reference (Mask R-CNN is a README bullet): standard head, parity unpinned.
+namespace md {
+__global__ void mask_select_kernel(const uint16_t *__restrict__ logits, const float *__restrict__ dets, int R, int SS, int C, int nc,
+                                   float *__restrict__ out) {
+    const size_t total = (size_t)R * SS;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e / SS);
+        const float score = dets[(size_t)r * 6 + 4];
+        const int label = (int)dets[(size_t)r * 6 + 5];
+        float v = 0.f;
+        if (score > 0.f && label >= 0 && label < nc) {
+            const float x = __uint_as_float((unsigned)logits[e * C + label] << 16);
+            v = 1.0f / (1.0f + expf(-x));
+        }
+        out[e] = v;
+    }
+}
+}  // namespace md
+
+extern "C" int md_mask_select(MD_AOT_ARGS) {
+    // in: logits[R,S,S,Cpad] bf16, dets[R,6] f32 ; out: masks[R,S,S] f32 ; extra: int32 num_classes
+    if (nparam != 3) return MD_ERR_NPARAM;
+    if (!params || !extra || !ndims || !shapes || ndims[0] != 4) return MD_ERR_ARG;
+    if (!md::dtype_is(dtypes, 0, "bfloat16") || !md::dtype_is(dtypes, 1, "float32") || !md::dtype_is(dtypes, 2, "float32")) return MD_ERR_ARG;
+    const int64_t R = shapes[0][0], S = shapes[0][1], C = shapes[0][3];
+    const int nc = *(const int32_t *)extra;
+    if (shapes[0][2] != S || nc < 1 || nc > C || md::numel(ndims, shapes, 1) != R * 6 || md::numel(ndims, shapes, 2) != R * S * S) return MD_ERR_ARG;
+    if (R * S * S == 0) return MD_OK;
+    if (!params[0] || !params[1] || !params[2]) return MD_ERR_ARG;
+    const size_t total = (size_t)R * S * S;
+    const size_t nb = (total + 255) / 256;
+    hipLaunchKernelGGL(md::mask_select_kernel, dim3((unsigned)(nb < 65535u * 64 ? nb : 65535u * 64)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)params[0], (const float *)params[1], (int)R, (int)(S * S), (int)C, nc, (float *)params[2]);
+    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
+}
+

@@ -693,3 +693,18 @@ def assign_targets(anchors, gt_boxes, gt_classes, matched_thr, unmatched_thr, an
     gt_ids = torch.empty((A,), dtype=torch.int32, device=dev)
     _lib.call("md_assign_targets", [a, g if G else None, cls if G else None, mt, ut, mask, labels, targets, weights, gt_ids])
     return labels, targets, weights, gt_ids
+
+
+def mask_select(logits, dets, num_classes):
+    """[R,S,S,Cpad] bf16 mask logits + [R,6] detections -> [R,S,S] f32 sigmoid of each detection's own class channel."""
+    r, sz = logits.shape[0], logits.shape[1]
+    out = torch.empty((r, sz, sz), dtype=torch.float32, device=logits.device)
+    _lib.call("md_mask_select", [logits, _f32c(dets).reshape(-1, 6), out], extra=ctypes.c_int32(int(num_classes)))
+    return out
+
+
+def dets_to_rois(dets):
+    """[B,D,6] detections -> [B*D,5] RoIs (batch index, x1, y1, x2, y2) for the mask head (layout plumbing)."""
+    B, D = dets.shape[0], dets.shape[1]
+    b = torch.arange(B, dtype=torch.float32, device=dets.device).view(B, 1, 1).expand(B, D, 1)
+    return torch.cat([b, dets[..., :4]], -1).reshape(B * D, 5).contiguous()

@@ -428,6 +428,71 @@ class DeconvModule:
         return nn_ops.conv_transpose2d(x, self.packed, out=out, c_off=c_off)
 
 
+@ROI_HEAD.register_module
+class FCNMaskHead:
+    """Mask R-CNN mask branch (He et al. 2017, FPN variant): RoIAlign 14x14 over P2..P5 on the final detections -> 4 x
+    [3x3 conv 256 + ReLU] -> Conv2dTranspose 2x2 s2 + ReLU -> 1x1 conv to num_classes -> the detection's own class channel,
+    sigmoid: [B, max_det, 28, 28].  Absent from the reference (Mask R-CNN is a README bullet): parity unpinned."""
+
+    def __init__(self, in_channels=256, conv_channels=256, num_convs=4, num_classes=80, roi_size=14, sampling_ratio=2,
+                 featmap_strides=(4, 8, 16, 32), seed=19, init=None):
+        init = init or ParamInit(seed)
+        self.nc, self.P, self.C = num_classes, roi_size, in_channels
+        self.convs = []
+        cin = in_channels
+        for _ in range(num_convs):
+            self.convs.append(ConvModule(init, cin, conv_channels, 3, 1, 1, bn=False, relu=True, bias=True))
+            cin = conv_channels
+        self.upsample = DeconvModule(init, cin, conv_channels, 2, 2, 0, bn=False, relu=True)
+        self.logits = ConvModule(init, conv_channels, num_classes, 1, bn=False, relu=False, bias=True, std=0.05)
+        self.strides, self.sampling = tuple(featmap_strides), sampling_ratio
+
+    def modules(self):
+        return self.convs + [self.upsample, self.logits]
+
+    def to(self, device):
+        for m in self.modules():
+            m.to(device)
+        return self
+
+    def __call__(self, feats, dets):
+        B, D = dets.shape[0], dets.shape[1]
+        rois = det_ops.dets_to_rois(dets)                                          # [B*D, 5]
+        x = det_ops.roi_align(list(feats[:len(self.strides)]), rois, self.P, [1.0 / s for s in self.strides], self.sampling, True)
+        for m in self.convs:
+            x = m(x)
+        x = self.logits(self.upsample(x))                                          # [B*D, 2P, 2P, nc (padded to 8)]
+        masks = det_ops.mask_select(x, dets.view(B * D, 6), self.nc)
+        return masks.view(B, D, 2 * self.P, 2 * self.P), dict(rois=rois, logits=x)
+
+
+@DETECTORS.register_module
+class MaskRCNN(FasterRCNN):
+    """Faster R-CNN + FCNMaskHead on the final detections: forward -> (dets [B,max_det,6], count [B], masks [B,max_det,28,28])."""
+
+    def __init__(self, backbone, neck, rpn_head, roi_head, mask_head, train_cfg=None, test_cfg=None):
+        super().__init__(backbone, neck, rpn_head, roi_head, train_cfg, test_cfg)
+        self.mask_head = build_roi_head(mask_head)
+
+    def to(self, device):
+        super().to(device)
+        self.mask_head.to(device)
+        return self
+
+    def conv_modules(self):
+        return super().conv_modules() + self.mask_head.modules()
+
+    def forward(self, images, return_aux=False):
+        dets, count, aux = FasterRCNN.forward(self, images, return_aux=True)
+        masks, aux_mask = self.mask_head(aux["feats"], dets)
+        if return_aux:
+            aux["mask"] = aux_mask
+            return dets, count, masks, aux
+        return dets, count, masks
+
+    __call__ = forward
+
+
 class DeformConvModule:
     """ModulatedDeformConv2d (DCNv2) + BatchNorm2d + ReLU -- centernet/src/resnet.py:24-106, used by the CenterNet neck
     (centernet_det.py:123-160): offset conv (3*k*k channels, has_bias) -> md_deform_cols -> 1x1 md_conv2d over the columns.

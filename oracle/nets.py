@@ -271,6 +271,32 @@ def deconv_module(m, x, quant=False):
     return _q(y, quant)
 
 
+def mask_head_forward(mh, feats, dets, quant=False):
+    """FCNMaskHead on the CPU.  feats: list of NCHW fp32 pyramid levels; dets [B,D,6] numpy (the boundary tensor: feed the
+    DEVICE detections so that upstream fp differences cannot move a RoI).  Returns masks [B,D,2P,2P] float32."""
+    B, D = dets.shape[0], dets.shape[1]
+    rois = np.concatenate([np.repeat(np.arange(B, dtype=np.float32), D)[:, None], dets.reshape(B * D, 6)[:, :4]], 1)
+    R = rois.shape[0]
+    fnp = [f.numpy() for f in feats[:len(mh.strides)]]
+    pooled = np.zeros((R, mh.C, mh.P, mh.P), np.float32)
+    lvl_of = np.clip(np_ops.fpn_level(rois[:, 1:]) - 2, 0, len(fnp) - 1)
+    for b in range(B):
+        for lvl in range(len(fnp)):
+            sel = np.nonzero((rois[:, 0] == b) & (lvl_of == lvl))[0]
+            if len(sel):
+                pooled[sel] = np_ops.roi_align_fast(fnp[lvl][b], rois[sel, 1:], mh.P, 1.0 / mh.strides[lvl], mh.sampling, True)
+    x = _q(torch.from_numpy(pooled), quant)
+    for m in mh.convs:
+        x = conv_module(m, x, quant=quant)
+    x = conv_module(mh.logits, deconv_module(mh.upsample, x, quant), quant=quant)     # [R, nc, 2P, 2P]
+    d = dets.reshape(B * D, 6)
+    out = np.zeros((R, 2 * mh.P, 2 * mh.P), np.float32)
+    for r in range(R):
+        if d[r, 4] > 0:
+            out[r] = torch.sigmoid(x[r, int(d[r, 5])]).numpy()
+    return out.reshape(B, D, 2 * mh.P, 2 * mh.P)
+
+
 def centernet_features(model, x, quant=False):
     """centernet/src/centernet_det.py:162-174 with the UNFUSED heads (three 3x3 + three 1x1 convs)."""
     f = resnet_forward(model.backbone, x, quant)[-1]
