@@ -200,6 +200,17 @@ typedef struct md_pool_attrs {
 } md_pool_attrs;
 /* in x[N,H,W,C] bf16 ; out y[N,Ho,Wo,C] bf16.  extra: md_pool_attrs (required). */
 int md_maxpool2d(MD_AOT_ARGS);
+/* YOLOv8 Detect decode (anchor-free, distribution focal loss bins; Ultralytics v8 convention; absent from the reference,
+ * BASELINE configs[3]: parity unpinned).  in head[B,H,W,Cp] bf16: channels [0, 4*reg_max) = (l,t,r,b) x reg_max bin logits,
+ * [4*reg_max, 4*reg_max + nc) = class logits ; out boxes[B,total,4] f32 (xyxy, pixels), scores[B,total] f32 (max class
+ * probability, -FLT_MAX at or below conf_thres), labels[B,total] i32; this level fills rows [out_offset, out_offset + H*W). */
+typedef struct md_yolov8_attrs {
+    int32_t num_classes, reg_max;
+    float stride, conf_thres;
+    int32_t out_offset, out_total;
+} md_yolov8_attrs;
+int md_yolov8_decode(MD_AOT_ARGS);
+
 /* Mask R-CNN: per-detection class channel of the mask head + sigmoid (absent from the reference: standard head, parity
  * unpinned).  in logits[R,S,S,Cpad] bf16, dets[R,6] f32 (x1,y1,x2,y2,score,label) ; out masks[R,S,S] f32 (zeros for empty
  * detection slots).  extra: int32 num_classes. */

@@ -781,6 +781,47 @@ __global__ void yolo_decode_kernel(const uint16_t *__restrict__ head, YoloArgs a
     labels[o] = lab;
 }
 
+// YOLOv8 Detect decode (anchor-free, DFL; Ultralytics v8 convention; absent from the reference: parity unpinned).
+// head [B,H,W,Cp] bf16: channels [0, 4*R) = box distribution logits (side-major: l, t, r, b x R bins), [4R, 4R+nc) = class
+// logits.  distance = sum_i i * softmax(bins)_i ; box = (ax - l, ay - t, ax + r, ay + b) * stride with the anchor point
+// (gx + 0.5, gy + 0.5); score = max_c sigmoid(cls_c), label = first arg-max; score <= conf -> -FLT_MAX.
+struct Yolo8Args { int H, W, Cp, nc, R; float stride, thr; int off, total; };
+__global__ void yolov8_decode_kernel(const uint16_t *__restrict__ head, Yolo8Args a, int B, float *__restrict__ boxes,
+                                     float *__restrict__ scores, int *__restrict__ labels) {
+    const int per = a.H * a.W;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * per) return;
+    const int b = e / per, loc = e % per;
+    const int gx = loc % a.W, gy = loc / a.W;
+    const uint16_t *h = head + ((size_t)b * per + loc) * a.Cp;
+    float d[4];
+#pragma unroll
+    for (int sd = 0; sd < 4; ++sd) {
+        float mx = -FLT_MAX;
+        for (int i = 0; i < a.R; ++i) mx = fmaxf(mx, rbf2f(h[sd * a.R + i]));
+        float den = 0.f, num = 0.f;
+        for (int i = 0; i < a.R; ++i) {
+            const float p = expf(rbf2f(h[sd * a.R + i]) - mx);
+            den += p;
+            num += p * (float)i;
+        }
+        d[sd] = num / den;
+    }
+    const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f;
+    float best = -FLT_MAX;
+    int lab = 0;
+    for (int c = 0; c < a.nc; ++c) {
+        const float v = rbf2f(h[4 * a.R + c]);
+        if (v > best) { best = v; lab = c; }
+    }
+    const float conf = 1.0f / (1.0f + expf(-best));  // sigmoid is monotonic: arg-max on the logits
+    const size_t o = (size_t)b * a.total + a.off + loc;
+    *reinterpret_cast<float4 *>(boxes + o * 4) =
+        make_float4((ax - d[0]) * a.stride, (ay - d[1]) * a.stride, (ax + d[2]) * a.stride, (ay + d[3]) * a.stride);
+    scores[o] = conf > a.thr ? conf : -FLT_MAX;
+    labels[o] = lab;
+}
+
 // rotated BEV box (x, y, dx, dy, r) -> axis-aligned "standup" box of its 4 corners:
 // pointpillars/src/core/box_np_ops.py:316-341 (center_to_corner_box2d, origin 0.5, corners @ [[c,-s],[s,c]])
 // + :172-177 (corner_to_standup_nd); call site pointpillars/src/predict.py:61-78.
@@ -1163,3 +1204,28 @@ extern "C" int md_sigmoid_clip(MD_AOT_ARGS) {
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }
+
+extern "C" int md_yolov8_decode(MD_AOT_ARGS) {
+    // in: head[B,H,W,Cp >= 4*reg_max + nc] bf16 ; out: boxes[B,total,4] f32, scores[B,total] f32, labels[B,total] i32
+    if (nparam != 4) return MD_ERR_NPARAM;
+    if (!params || !extra || !ndims || !shapes || ndims[0] != 4) return MD_ERR_ARG;
+    if (!dtype_is(dtypes, 0, "bfloat16") || !dtype_is(dtypes, 1, "float32") || !dtype_is(dtypes, 2, "float32") || !dtype_is(dtypes, 3, "int32"))
+        return MD_ERR_ARG;
+    const md_yolov8_attrs *at = (const md_yolov8_attrs *)extra;
+    Yolo8Args a;
+    const int B = (int)shapes[0][0];
+    a.H = (int)shapes[0][1]; a.W = (int)shapes[0][2]; a.Cp = (int)shapes[0][3];
+    a.nc = at->num_classes; a.R = at->reg_max; a.stride = at->stride; a.thr = at->conf_thres; a.off = at->out_offset; a.total = at->out_total;
+    const int per = a.H * a.W;
+    if (a.nc < 1 || a.R < 1 || a.R > 64 || 4 * a.R + a.nc > a.Cp || a.off < 0 || a.off + per > a.total) return MD_ERR_ARG;
+    if (numel(ndims, shapes, 1) != (int64_t)B * a.total * 4 || numel(ndims, shapes, 2) != (int64_t)B * a.total ||
+        numel(ndims, shapes, 3) != (int64_t)B * a.total)
+        return MD_ERR_ARG;
+    if ((int64_t)B * per == 0) return MD_OK;
+    if ((int64_t)B * per > 0x7fffffffLL) return MD_ERR_SIZE;
+    hipLaunchKernelGGL(yolov8_decode_kernel, dim3((unsigned)((B * per + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t *)params[0], a, B, (float *)params[1], (float *)params[2], (int *)params[3]);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+

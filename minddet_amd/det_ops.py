@@ -708,3 +708,13 @@ def dets_to_rois(dets):
     B, D = dets.shape[0], dets.shape[1]
     b = torch.arange(B, dtype=torch.float32, device=dets.device).view(B, 1, 1).expand(B, D, 1)
     return torch.cat([b, dets[..., :4]], -1).reshape(B * D, 5).contiguous()
+
+
+class _Yolo8Attrs(ctypes.Structure):
+    _fields_ = [("num_classes", ctypes.c_int32), ("reg_max", ctypes.c_int32), ("stride", ctypes.c_float), ("conf_thres", ctypes.c_float),
+                ("out_offset", ctypes.c_int32), ("out_total", ctypes.c_int32)]
+
+
+def yolov8_decode(head, boxes, scores, labels, num_classes, reg_max, stride, conf_thres, out_offset, out_total):
+    _lib.call("md_yolov8_decode", [head, boxes, scores, labels],
+              extra=_Yolo8Attrs(int(num_classes), int(reg_max), float(stride), float(conf_thres), int(out_offset), int(out_total)))

@@ -821,3 +821,154 @@ class YOLOv5:
         return dets, count
 
     __call__ = forward
+
+
+# ----------------------------------------------------------------------------- YOLOv8 (BASELINE configs[3]; parity unpinned)
+class C2f:
+    """Ultralytics C2f: cv2(concat(y0, y1, m1(y1), m2(m1(y1)), ...)) with (y0, y1) = chunk(cv1(x), 2) and m = n x
+    [x (+) 3x3(3x3(x))].  cv1 is stored as its two output halves (cv1a, cv1b: the same arithmetic as one 2c-channel 1x1
+    conv followed by chunk), so that y0 is written straight into the concat buffer and y1 is a compact tensor."""
+
+    def __init__(self, init, c1, c2, n=1, shortcut=False):
+        c = c2 // 2
+        self.c, self.n, self.shortcut = c, n, shortcut
+        self.cv1a, self.cv1b = _yconv(init, c1, c, 1), _yconv(init, c1, c, 1)
+        self.cv2 = _yconv(init, (2 + n) * c, c2, 1)
+        self.m = [(_yconv(init, c, c, 3), _yconv(init, c, c, 3)) for _ in range(n)]
+
+    def modules(self):
+        return [self.cv1a, self.cv1b, self.cv2] + [m for pair in self.m for m in pair]
+
+    def __call__(self, x):
+        n, h, w, _ = x.shape
+        cat = torch.empty((n, h, w, (2 + self.n) * self.c), dtype=torch.bfloat16, device=x.device)
+        self.cv1a(x, out=cat, c_off=0)
+        y = self.cv1b(x)
+        nn_ops.concat_copy(y, cat, self.c)
+        for i, (a, b) in enumerate(self.m):
+            if self.shortcut:
+                y = b(a(y), residual=y)          # SiLU first, then the shortcut add
+                nn_ops.concat_copy(y, cat, (2 + i) * self.c)
+            elif i == len(self.m) - 1:
+                b(a(y), out=cat, c_off=(2 + i) * self.c)
+            else:
+                y = b(a(y))
+                nn_ops.concat_copy(y, cat, (2 + i) * self.c)
+        return self.cv2(cat)
+
+
+@DETECTORS.register_module
+class YOLOv8:
+    """YOLOv8 (Ultralytics v8.0 yolov8.yaml): CSP backbone with C2f blocks + SPPF, PAN head, anchor-free Detect with DFL
+    (reg_max 16); decode + class-aware NMS (conf 0.25 / IoU 0.7 / max_det 300).  depth / width / max_channels 1.0 / 1.0 / 512
+    = yolov8l."""
+
+    def __init__(self, depth_multiple=1.0, width_multiple=1.0, max_channels=512, num_classes=80, reg_max=16, conf_thres=0.25,
+                 iou_thres=0.7, max_det=300, nms_pre=4096, seed=7, train_cfg=None, test_cfg=None):
+        init = ParamInit(seed)
+        ch = lambda c: max(8, int(math.ceil(min(c, max_channels) * width_multiple / 8) * 8))
+        d = lambda n: max(1, round(n * depth_multiple))
+        c64, c128, c256, c512, c1024 = ch(64), ch(128), ch(256), ch(512), ch(1024)
+        self.b0 = _yconv(init, 3, c64, 3, 2)
+        self.b1 = _yconv(init, c64, c128, 3, 2)
+        self.b2 = C2f(init, c128, c128, d(3), True)
+        self.b3 = _yconv(init, c128, c256, 3, 2)
+        self.b4 = C2f(init, c256, c256, d(6), True)
+        self.b5 = _yconv(init, c256, c512, 3, 2)
+        self.b6 = C2f(init, c512, c512, d(6), True)
+        self.b7 = _yconv(init, c512, c1024, 3, 2)
+        self.b8 = C2f(init, c1024, c1024, d(3), True)
+        self.b9 = SPPF(init, c1024, c1024)
+        self.h12 = C2f(init, c1024 + c512, c512, d(3))
+        self.h15 = C2f(init, c512 + c256, c256, d(3))
+        self.h16 = _yconv(init, c256, c256, 3, 2)
+        self.h18 = C2f(init, c256 + c512, c512, d(3))
+        self.h19 = _yconv(init, c512, c512, 3, 2)
+        self.h21 = C2f(init, c512 + c1024, c1024, d(3))
+        self.nc, self.reg_max = num_classes, reg_max
+        c2 = max(16, c256 // 4, 4 * reg_max)
+        c3 = max(c256, min(num_classes, 100))
+        self.head_c = (4 * reg_max + num_classes + 7) // 8 * 8
+        self.box, self.cls = [], []
+        for c in (c256, c512, c1024):
+            self.box.append([_yconv(init, c, c2, 3), _yconv(init, c2, c2, 3),
+                             ConvModule(init, c2, 4 * reg_max, 1, bn=False, relu=False, bias=True, std=0.05, bias_value=1.0)])
+            self.cls.append([_yconv(init, c, c3, 3), _yconv(init, c3, c3, 3),
+                             ConvModule(init, c3, num_classes, 1, bn=False, relu=False, bias=True, std=0.05)])
+        self.strides = (8, 16, 32)
+        self.conf_thres, self.iou_thres, self.max_det, self.nms_pre = conf_thres, iou_thres, max_det, nms_pre
+        self._seg = {}
+
+    def conv_modules(self):
+        out = [self.b0, self.b1, self.b3, self.b5, self.b7, self.h16, self.h19]
+        for blk in (self.b2, self.b4, self.b6, self.b8, self.b9, self.h12, self.h15, self.h18, self.h21):
+            out += blk.modules()
+        for br in self.box + self.cls:
+            out += br
+        return out
+
+    def to(self, device):
+        for m in self.conv_modules():
+            m.to(device)
+        return self
+
+    @staticmethod
+    def _up_cat(top, skip):
+        n, h, w, c = skip.shape
+        ct = top.shape[3]
+        cat = torch.empty((n, h, w, ct + c), dtype=torch.bfloat16, device=skip.device)
+        nn_ops.upsample2x(top, cat, 0)
+        nn_ops.concat_copy(skip, cat, ct)
+        return cat
+
+    def features(self, x):
+        x = self.b2(self.b1(self.b0(x)))
+        p3 = self.b4(self.b3(x))
+        p4 = self.b6(self.b5(p3))
+        p5 = self.b9(self.b8(self.b7(p4)))
+        h12 = self.h12(self._up_cat(p5, p4))
+        o3 = self.h15(self._up_cat(h12, p3))
+        n, h, w, c = h12.shape
+        cat = torch.empty((n, h, w, o3.shape[3] + c), dtype=torch.bfloat16, device=x.device)
+        self.h16(o3, out=cat, c_off=0)
+        nn_ops.concat_copy(h12, cat, o3.shape[3])
+        o4 = self.h18(cat)
+        n, h, w, c = p5.shape
+        cat = torch.empty((n, h, w, o4.shape[3] + c), dtype=torch.bfloat16, device=x.device)
+        self.h19(o4, out=cat, c_off=0)
+        nn_ops.concat_copy(p5, cat, o4.shape[3])
+        o5 = self.h21(cat)
+        heads = []
+        for f, bx, cl in zip((o3, o4, o5), self.box, self.cls):
+            n, h, w, _ = f.shape
+            head = torch.zeros((n, h, w, self.head_c), dtype=torch.bfloat16, device=f.device)
+            bx[2](bx[1](bx[0](f)), out=head, c_off=0)                       # 4 * reg_max distribution logits
+            cl[2](cl[1](cl[0](f)), out=head, c_off=4 * self.reg_max)        # class logits
+            heads.append(head)
+        return heads
+
+    def forward(self, images, return_aux=False):
+        heads = self.features(images)
+        B, dev = images.shape[0], images.device
+        total = sum(h.shape[1] * h.shape[2] for h in heads)
+        boxes = torch.empty((B, total, 4), dtype=torch.float32, device=dev)
+        scores = torch.empty((B, total), dtype=torch.float32, device=dev)
+        labels = torch.empty((B, total), dtype=torch.int32, device=dev)
+        off = 0
+        for h, s in zip(heads, self.strides):
+            det_ops.yolov8_decode(h, boxes, scores, labels, self.nc, self.reg_max, s, self.conf_thres, off, total)
+            off += h.shape[1] * h.shape[2]
+        if (B, total) not in self._seg:
+            self._seg[(B, total)] = torch.arange(0, (B + 1) * total, total, dtype=torch.int32, device=dev)
+        sv, si, sc = det_ops.topk_segmented(scores, self._seg[(B, total)], self.nms_pre, max_segment=total)
+        sb = det_ops.gather_rows(boxes, si, sc)
+        sl = torch.gather(labels, 1, si.long())
+        keep, kidx, num = det_ops.nms_aligned(sb, self.iou_thres, mode=det_ops.NMS_MODE_STRICT, count=sc, group=sl, max_output=self.max_det)
+        dets, count = det_ops.pack_detections(sb, sv, sl, kidx, num, self.max_det)
+        if return_aux:
+            return dets, count, dict(heads=heads, boxes=boxes, scores=scores, labels=labels, sel_idx=si, sel_cnt=sc, sel_boxes=sb,
+                                     sel_labels=sl, keep=keep)
+        return dets, count
+
+    __call__ = forward
+

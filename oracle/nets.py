@@ -372,3 +372,46 @@ def yolo_decode_np(head_nhwc, nc, na, stride, anchors, conf_thres):
     ok = (obj > np.float32(conf_thres)) & (conf > np.float32(conf_thres))
     boxes = np.stack([cx - w / 2, cy - hh / 2, cx + w / 2, cy + hh / 2], -1).reshape(B, -1, 4).astype(np.float32)
     return boxes, np.where(ok, conf, -np.inf).reshape(B, -1).astype(np.float32), lab.reshape(B, -1).astype(np.int32)
+
+
+# ----------------------------------------------------------------------------- YOLOv8 oracle (parity unpinned)
+def _c2f(blk, x, quant):
+    ys = [conv_module(blk.cv1a, x, quant=quant), conv_module(blk.cv1b, x, quant=quant)]
+    for a, b in blk.m:
+        t = conv_module(a, ys[-1], quant=quant)
+        ys.append(conv_module(b, t, residual=ys[-1] if blk.shortcut else None, quant=quant))
+    return conv_module(blk.cv2, torch.cat(ys, 1), quant=quant)
+
+
+def yolov8_heads(m, x, quant=False):
+    """-> per level NCHW [B, 4*reg_max + nc, H, W] (box distribution logits, then class logits)."""
+    cm = lambda mod, t: conv_module(mod, t, quant=quant)
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
+    x = _c2f(m.b2, cm(m.b1, cm(m.b0, x)), quant)
+    p3 = _c2f(m.b4, cm(m.b3, x), quant)
+    p4 = _c2f(m.b6, cm(m.b5, p3), quant)
+    p5 = _sppf(m.b9, _c2f(m.b8, cm(m.b7, p4), quant), quant)
+    h12 = _c2f(m.h12, torch.cat([up(p5), p4], 1), quant)
+    o3 = _c2f(m.h15, torch.cat([up(h12), p3], 1), quant)
+    o4 = _c2f(m.h18, torch.cat([cm(m.h16, o3), h12], 1), quant)
+    o5 = _c2f(m.h21, torch.cat([cm(m.h19, o4), p5], 1), quant)
+    outs = []
+    for f, bx, cl in zip((o3, o4, o5), m.box, m.cls):
+        outs.append(torch.cat([cm(bx[2], cm(bx[1], cm(bx[0], f))), cm(cl[2], cm(cl[1], cm(cl[0], f)))], 1))
+    return outs
+
+
+def yolov8_decode_np(head_nhwc, nc, reg_max, stride, conf_thres):
+    """head [B,H,W,C >= 4*reg_max + nc] float32 -> boxes [B,HW,4], scores [B,HW] (-inf where rejected), labels [B,HW]."""
+    B, H, W, _ = head_nhwc.shape
+    d = head_nhwc[..., :4 * reg_max].reshape(B, H, W, 4, reg_max).astype(np.float32)
+    p = np.exp(d - d.max(-1, keepdims=True))
+    dist = (p * np.arange(reg_max, dtype=np.float32)).sum(-1) / p.sum(-1)
+    gy, gx = np.meshgrid(np.arange(H, dtype=np.float32) + 0.5, np.arange(W, dtype=np.float32) + 0.5, indexing="ij")
+    s = np.float32(stride)
+    boxes = np.stack([(gx[None] - dist[..., 0]) * s, (gy[None] - dist[..., 1]) * s, (gx[None] + dist[..., 2]) * s,
+                      (gy[None] + dist[..., 3]) * s], -1).reshape(B, -1, 4).astype(np.float32)
+    cls = head_nhwc[..., 4 * reg_max:4 * reg_max + nc].astype(np.float32)
+    lab = cls.argmax(-1)
+    conf = (1.0 / (1.0 + np.exp(-cls.max(-1).astype(np.float64)))).astype(np.float32)
+    return boxes, np.where(conf > np.float32(conf_thres), conf, -np.inf).reshape(B, -1).astype(np.float32), lab.reshape(B, -1).astype(np.int32)

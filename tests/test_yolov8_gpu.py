@@ -1,0 +1,74 @@
+"""-m gpu: YOLOv8 graph (BASELINE configs[3]; build-authored, parity unpinned: YOLO is a README bullet in the reference).
+Conv stack (C2f with in-place concat slices, SPPF, PAN, decoupled DFL / class heads) vs torch fp32 with bf16 storage;
+anchor-free DFL decode vs numpy; top-k / class-aware NMS / packing bit-exact from the device tensors."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import nets, np_ops
+from tests.conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs MI355X")]
+DEV = "cuda:0"
+
+
+def test_yolov8_tiny_end_to_end():
+    from minddet.models import Config, build_detector
+
+    cfg = Config.fromfile("configs/yolov8/yolov8_tiny.py")
+    cfg.model["conf_thres"] = 0.3
+    m = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    x = torch.zeros((2, 128, 160, 8))
+    x[..., :3] = torch.randn((2, 128, 160, 3), generator=g)
+    xb = x.to(torch.bfloat16)
+    dets, count, aux = m.forward(xb.to(DEV), return_aux=True)
+    torch.cuda.synchronize()
+    assert [tuple(h.shape[1:3]) for h in aux["heads"]] == [(16, 20), (8, 10), (4, 5)]
+    ref = nets.yolov8_heads(m, xb[..., :3].float().permute(0, 3, 1, 2).contiguous(), quant=True)
+    for hd, hr in zip(aux["heads"], ref):
+        got = hd.float().cpu().permute(0, 3, 1, 2)[:, :hr.shape[1]]
+        rms = hr.pow(2).mean().sqrt().item()
+        err = (got - hr).abs().max().item()
+        assert err <= 6e-2 * (rms + 0.1 * hr.abs().max().item() + 1e-3), (err, rms)
+    off = 0
+    sd, bd, ld = aux["scores"].cpu().numpy(), aux["boxes"].cpu().numpy(), aux["labels"].cpu().numpy()
+    for hd, s in zip(aux["heads"], m.strides):
+        b_o, s_o, l_o = nets.yolov8_decode_np(hd.float().cpu().numpy(), m.nc, m.reg_max, s, m.conf_thres)
+        n = b_o.shape[1]
+        s_d = np.where(sd[:, off:off + n] < -1e30, -np.inf, sd[:, off:off + n])
+        np.testing.assert_allclose(bd[:, off:off + n], b_o, rtol=2e-5, atol=2e-3)
+        both = np.isfinite(s_d) & np.isfinite(s_o)
+        assert (np.isfinite(s_d) != np.isfinite(s_o)).mean() < 1e-3
+        np.testing.assert_allclose(s_d[both], s_o[both], rtol=3e-6, atol=1e-7)
+        assert (ld[:, off:off + n] == l_o).mean() > 0.999
+        off += n
+    assert int(aux["sel_cnt"].sum()) > 0
+    d = dets.cpu().numpy()
+    for b in range(2):
+        sc = np.where(sd[b] < -1e30, -np.inf, sd[b])
+        v, i = np_ops.topk_desc_stable(sc, m.nms_pre)
+        k = min(m.nms_pre, int(np.isfinite(sc).sum()))
+        v, i = v[:k], i[:k]
+        assert int(aux["sel_cnt"][b]) == k
+        np.testing.assert_array_equal(aux["sel_idx"].cpu().numpy()[b, :k], i)
+        keep = oracle.nms_aligned(bd[b][i], m.iou_thres, 0.0, 2, groups=ld[b][i]).astype(bool)
+        kidx = np.nonzero(keep)[0][:m.max_det]
+        assert int(count[b]) == len(kidx)
+        np.testing.assert_array_equal(d[b, :len(kidx), :4], bd[b][i][kidx])
+
+
+def test_yolov8l_full_size_structure():
+    from minddet.models import Config, build_detector
+    from minddet_amd.data import synthetic_images
+
+    cfg = Config.fromfile("configs/yolov8/yolov8l.py")
+    m = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(DEV)
+    x = synthetic_images(2, 640, 640, device=DEV)
+    dets, count, aux = m.forward(x, return_aux=True)
+    dets2, count2 = m.forward(x)
+    torch.cuda.synchronize()
+    assert [tuple(h.shape[1:4]) for h in aux["heads"]] == [(80, 80, 144), (40, 40, 144), (20, 20, 144)]
+    assert aux["boxes"].shape == (2, 8400, 4) and dets.shape == (2, 300, 6)
+    assert torch.equal(dets, dets2) and torch.equal(count, count2)
