@@ -168,14 +168,14 @@ def main():
         t_roof_ms = sum(max(r[2] / (PEAK_BF16_TFLOPS * 1e12), r[6] / PEAK_HBM_BPS) for r in records) * 1e3
         traffic = all_traffic = None
         tp = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-        PMC_NAMES = {1: "conv_pingpong_kernel<0, 0>", 2: "conv_igemm_kernel<256, 2, 2, 2, 2, 2, 0, 0>"}
+        PMC_PREFIX = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<256, 2, 2, 2, 2, 2,"}  # all instantiations of the kernel
         if os.path.exists(tp):  # PMC passes are separate rocprofv3 runs (tools/pmc_traffic.py); same config only
             tj = json.load(open(tp))
             if tj.get("batch_per_gpu") == B and type(model).__name__ == "FasterRCNN":
                 all_traffic = round(tj["hbm_bytes_per_launch"] / 1e6, 2)
-                bk = tj.get("by_kernel", {}).get(PMC_NAMES.get(dom, ""))
-                if bk:
-                    traffic = round(bk["hbm_bytes_per_launch"] / 1e6, 2)
+                sel = [v for k_, v in tj.get("by_kernel", {}).items() if dom in PMC_PREFIX and k_.startswith(PMC_PREFIX[dom])]
+                if sel:
+                    traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / sum(v["launches"] for v in sel) / 1e6, 2)
         roofline = {"bound": "hbm" if hbm_bound else "mfma",
                     "kernel": KNAMES.get(dom, str(dom)) + " (dominant kernel: %.0f %% of the conv/FC time)" % (100 * d_ms / tot_ms),
                     "achieved": round(ach, 2), "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(ach / peak, 4),
