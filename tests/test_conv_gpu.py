@@ -218,3 +218,27 @@ def test_conv2d_head_fused_vs_two_launches(shape):
     rms = ref.pow(2).mean().sqrt().item()
     assert ((y[..., :15] - ref).abs() <= 1.5e-2 * ref.abs() + 1.5e-2 * rms).all()
     assert ((y - y_two).abs() <= 1.0e-2 * y_two.abs() + 1.0e-2 * rms).all()
+
+
+def test_conv2d_head_batch_chunking_is_bit_identical():
+    """The fused RPN head through the image-chunked path (lowered limit) equals the single-launch result."""
+    import ctypes
+
+    from minddet_amd import _lib, nn_ops
+
+    g = torch.Generator().manual_seed(41)
+    pc = nn_ops.pack_conv(torch.randn((256, 256, 3, 3), generator=g) * 0.02, bias=torch.randn((256,), generator=g) * 0.1,
+                          stride=1, pad=1, relu=True).to(DEV)
+    pc2 = nn_ops.pack_conv(torch.randn((15, 256, 1, 1), generator=g) * 0.05, bias=torch.randn((15,), generator=g) * 0.1).to(DEV)
+    x = torch.randn((3, 96, 96, 256), generator=g).to(torch.bfloat16).to(DEV)
+    y0 = nn_ops.conv2d_head(x, pc, pc2)
+    fn = _lib.lib().md_conv2d_set_chunk_limit
+    fn.restype, fn.argtypes = ctypes.c_longlong, [ctypes.c_longlong]
+    old = fn(2 * 96 * 96 * 256 * 2 + 1)   # two images per chunk: the second chunk (one image, 36 tiles) takes the two-launch path
+    try:
+        y1 = nn_ops.conv2d_head(x, pc, pc2)
+    finally:
+        fn(old)
+    torch.cuda.synchronize()
+    assert torch.equal(y0[:2], y1[:2])
+    assert (y0[2].float() - y1[2].float()).abs().max().item() <= 2e-2 * (1 + y0[2].float().abs().max().item())

@@ -75,6 +75,17 @@ def test_size_limits_and_bad_arguments_return_codes():
         _lib.call("md_stem_pool", [torch.zeros((1, 48, 80, 8), dtype=torch.bfloat16, device=DEV), ps.w, ps.bias,
                                    torch.zeros((1, 8, 16, 64), dtype=torch.bfloat16, device=DEV)])      # 8-channel input
     assert nn_ops.stem_pool(torch.zeros((0, 32 + 16, 64 + 16, 4), dtype=torch.bfloat16, device=DEV), ps).shape == (0, 8, 16, 64)
+    # md_deform_cols: the offset tensor must carry 3*k*k channels ; md_image_preprocess: uint8 HWC input only
+    with pytest.raises(_lib.MindDetHipError, match="rc=2"):
+        _lib.call("md_deform_cols", [torch.zeros((1, 8, 8, 64), dtype=torch.bfloat16, device=DEV),
+                                     torch.zeros((1, 8, 8, 24), dtype=torch.bfloat16, device=DEV),
+                                     torch.zeros((1, 8, 8, 576), dtype=torch.bfloat16, device=DEV)], extra=nn_ops._PoolAttrs3(3, 1, 1, 0))
+    with pytest.raises(_lib.MindDetHipError, match="rc=2"):
+        nn_ops.image_preprocess(torch.zeros((1, 8, 8, 3), dtype=torch.float32, device=DEV),
+                                torch.zeros((1, 6), dtype=torch.float32, device=DEV), (0, 0, 0), (1, 1, 1), (16, 64))
+    # md_assign_targets: more ground-truth boxes than the kernel's LDS table -> size error
+    with pytest.raises(_lib.MindDetHipError, match="rc=4"):
+        det_ops.assign_targets(torch.zeros((8, 7), device=DEV), torch.ones((1025, 7), device=DEV), None, 0.6, 0.45)
 
 
 def test_caller_workspace_is_used():
