@@ -63,7 +63,7 @@ def main():
     from minddet.models import Config, build_detector
     from minddet_amd import _lib, nn_ops
     from minddet_amd.data import synthetic_images
-    from minddet_amd.shard import gather_detections
+    from minddet_amd.shard import gather_detections, gather_masks
 
     cfg = Config.fromfile(args.config)
     model = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(dev)
@@ -119,8 +119,10 @@ def main():
             x = nn_ops.image_preprocess(images_u8, pre_mat, (0.408, 0.447, 0.470), (0.289, 0.274, 0.278), (H, W),
                                         stem_layout=images.shape[3] == 4)
         out = model.forward(x)
-        dets, count = out[0], out[1]   # Mask R-CNN also returns masks [B,max_det,28,28]; they stay on their shard
+        dets, count = out[0], out[1]
         if use_dist:
+            if len(out) > 2:   # Mask R-CNN: the 28x28 masks travel as fp16 in a second fixed-shape all_gather
+                gather_masks(out[2], force=True)
             return gather_detections(dets, count, force=True)
         return dets, count
 

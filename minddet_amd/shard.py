@@ -47,3 +47,16 @@ def gather_detections(dets, count, group=None, force=False):
     out = torch.empty((world * buf.shape[0],) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
     dist.all_gather_into_tensor(out, buf, group=group)
     return unpack_gathered(out)
+
+
+def gather_masks(masks, group=None, force=False):
+    """Mask R-CNN: the per-detection 28x28 masks of the whole global batch as fp16 [B_total, max_det, S, S] ("masks
+    gathered as 28x28 fp16 per det ... never full-resolution"), a second fixed-shape all_gather next to gather_detections."""
+    m16 = masks.to(torch.float16).contiguous()
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
+        return m16
+    world = dist.get_world_size(group)
+    out = torch.empty((world * m16.shape[0],) + tuple(m16.shape[1:]), dtype=m16.dtype, device=m16.device)
+    dist.all_gather_into_tensor(out, m16, group=group)
+    return out
+

@@ -31,6 +31,9 @@ def _worker(rank, world, port, q):
     lo, hi = shard.shard_range(B, rank, world)
     d, c = shard.gather_detections(dets_all[lo:hi].contiguous(), count_all[lo:hi].contiguous())
     ok = torch.equal(d, dets_all) and torch.equal(c, count_all)
+    masks_all = torch.rand((B, M, 28, 28), generator=g)
+    mg = shard.gather_masks(masks_all[lo:hi].contiguous())
+    ok = ok and mg.dtype == torch.float16 and torch.equal(mg, masks_all.to(torch.float16))
     q.put((rank, ok, tuple(d.shape)))
     dist.destroy_process_group()
 
