@@ -9,11 +9,15 @@ followed, when N > 1, by the single all_gather of the padded detections (SURVEY 
 sharded across ranks (weak scaling: B images per GPU); value = N*B*K / max-over-ranks time.
 
 The JSON line also carries
-  roofline     -- the dominant kernel (conv_igemm, MFMA-bound): algorithmic FLOPs of every conv/FC
-                  launch in the timed region / the sum of their durations, each launch bracketed by
-                  HIP events on the launch stream; peak = 2.5 PFLOP/s dense bf16.
-  cpu_baseline -- the oracle's plain fp32 torch-CPU restatement of the same graph (oracle/nets.py)
-                  timed on this host's cores on ONE image (rank 0, N=1 only).
+  roofline     -- the DOMINANT conv kernel by time (md_conv2d_last_kernel attributes every launch; each is bracketed by
+                  HIP events on the launch stream) against the roofline that binds its launches in aggregate
+                  (algorithmic flops / 2.5 PFLOP/s dense bf16 or algorithmic bytes / 8 TB/s), its PMC traffic from
+                  profiles/r01_conv_traffic.json, and under "all_conv" the same per kernel and for the whole conv/FC set
+                  (incl. frac_of_layerwise_roofline = sum of per-launch max(flops/peak, bytes/peak) / measured time).
+  cpu_baseline -- the oracle's plain fp32 torch-CPU restatement of the same graph (oracle/nets.py) timed on this
+                  host's cores on a bounded sample (rank 0, N=1 only).
+The batch is resident in HBM in the model's input layout (zero-bordered 4-channel NHWC for the fused stem) before the timed
+region; --from-uint8 also times md_image_preprocess from a resident uint8 batch.
 """
 import argparse
 import json

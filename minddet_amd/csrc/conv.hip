@@ -15,11 +15,17 @@
 // bf16x4 (ds_write_b64) into a [pixel][cout] LDS image and the tile leaves the CU as whole
 // 16-byte / 128-B-line NHWC stores, with bias, residual and ReLU fused.
 //
-// Workgroup = 256 threads = 4 wave64; tile = (WC*FC*32 couts) x (WP*FP*32 pixels) x BK 64;
-// v_mfma_f32_32x32x16_bf16; LDS tiles are [row][64 k] bf16 (128-B rows) with the 16-B chunk
-// index XOR-swizzled by (row>>1)&7 so that both the ds_write_b128 staging stores and the
-// ds_read_b128 fragment reads are bank-conflict free; double-buffered, one barrier per K tile,
-// next tile's global loads issued before the MFMAs of the current one.
+// Three kernels (dispatcher + cost model at the end of the file):
+//   conv_pingpong_kernel  256 x 256 x 64 tile, one 8-wave workgroup per CU, two staggered wave groups, LDS-DMA stream
+//                         with counted vmcnt -- the MFMA-bound layers (K >= 1024, Cout % 256 == 0), optionally with a
+//                         fused 1x1 head out of the epilogue image (md_conv2d_head);
+//   conv_igemm_kernel     128 x 128 x 64 (or 64- / 32-cout) tile, 4 waves, ONE LDS staging buffer -> four resident
+//                         workgroups per CU -- everything else;
+//   conv3x3_halo_kernel   3x3 / s1 layers with Cout <= 64: the 10 x 18 halo staged once per 64-channel chunk.
+// Common: v_mfma_f32_32x32x16_bf16; LDS tiles [row][64 k] bf16 (128-B rows) with the 16-B chunk index XOR-swizzled by
+// (row>>1)&7 (applied to the DMA's SOURCE chunk and to the ds_read_b128 fragment reads: conflict free); epilogue = bias
+// from LDS (requested at kernel start) -> packed adds -> v_cvt_pk_bf16_f32 -> packed ReLU -> LDS transpose -> +residual
+// -> non-temporal 16-B stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
