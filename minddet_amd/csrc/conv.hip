@@ -1221,7 +1221,9 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
         const long long x_img = shapes[0][1] * shapes[0][2] * shapes[0][3] * 2;
         if (n_img > 1 && x_img > 0 && x_img < g_chunk_limit && n_img * x_img >= g_chunk_limit && shapes[4][0] == n_img &&
             (!params[3] || (ndims[3] == 4 && shapes[3][0] == n_img))) {
-            const long long per = g_chunk_limit / x_img;  // images per chunk (>= 1)
+            const long long per_max = g_chunk_limit / x_img;                 // images a chunk may hold (>= 1)
+            const long long n_chunks = (n_img + per_max - 1) / per_max;
+            const long long per = (n_img + n_chunks - 1) / n_chunks;          // even split: no tiny last chunk
             const long long y_img = shapes[4][1] * shapes[4][2] * shapes[4][3] * 2;
             const long long r_img = params[3] ? shapes[3][1] * shapes[3][2] * shapes[3][3] * 2 : 0;
             for (long long n0 = 0; n0 < n_img; n0 += per) {
