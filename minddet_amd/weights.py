@@ -264,3 +264,97 @@ def load_centernet(model, params, naming="auto", strict=True):
         set_attr(c2, "bias", f"network.{name}_fn.2.bias")
     model.fuse_heads()
     return sorted(k for k in params if k not in used)
+
+
+# ----------------------------------------------------------------------------- CenterPoint / PointPillars
+def torch_to_ms_generic(names):
+    """det3d (torch) state-dict keys -> the reference's MindSpore keys, the rule of CenterPoint's `convert()`
+    (centerpoint/det3d_ms/models/detectors/point_pillars.py:137-168): `num_batches_tracked` / `global_step` dropped;
+    `running_mean` -> `moving_mean`, `running_var` -> `moving_variance`; `weight` -> `gamma` and `bias` -> `beta` ONLY for
+    BatchNorm layers, recognised by a sibling `running_var` key (a conv / dense `weight` or `bias` keeps its name).
+    Returns {torch key: MindSpore key} for the kept keys."""
+    keys = set(names)
+    out = {}
+    for k in sorted(keys):
+        if "num_batches_tracked" in k or "global_step" in k:
+            continue
+        if "running_mean" in k:
+            out[k] = k.replace("running_mean", "moving_mean")
+        elif "running_var" in k:
+            out[k] = k.replace("running_var", "moving_variance")
+        elif "bias" in k:
+            out[k] = k.replace("bias", "beta") if k.replace("bias", "running_var") in keys else k
+        elif "weight" in k:
+            out[k] = k.replace("weight", "gamma") if k.replace("weight", "running_var") in keys else k
+        else:
+            out[k] = k
+    return out
+
+
+def strip_net_prefix(params):
+    """PointPillars' `get_params_for_net` (pointpillars/src/utils.py:48-56): a training checkpoint stores the network under
+    `network.network.` (TrainOneStepCell(WithLossCell(net))) and optimizer copies under `optimizer.`; both prefixes are
+    stripped, every other key is dropped."""
+    out = {}
+    for k, v in params.items():
+        if k.startswith("optimizer."):
+            out[k[10:]] = v
+        elif k.startswith("network.network."):
+            out[k[16:]] = v
+    return out
+
+
+def _rpn_slots(model, prefix):
+    """(module, key prefix of its conv, key prefix of its BN) for every layer of graphs.RPN under the reference's cell names
+    (centerpoint/det3d_ms/models/necks/rpn.py:114-143: block i = SequentialCell[Pad, Conv, BN, ReLU, (Conv, BN, ReLU) x n] ->
+    conv at 1 + 3j, BN at 2 + 3j; :60-105: deblock k = SequentialCell[Conv2dTranspose | Conv2d, BN, ReLU] -> 0 and 1)."""
+    slots = []
+    for i, blk in enumerate(model.blocks):
+        for j, m in enumerate(blk):
+            slots.append((m, f"{prefix}blocks.{i}.{1 + 3 * j}", f"{prefix}blocks.{i}.{2 + 3 * j}"))
+    for k, m in enumerate(model.deblocks):
+        slots.append((m, f"{prefix}deblocks.{k}.0", f"{prefix}deblocks.{k}.1"))
+    return slots
+
+
+def rpn_state(model, prefix="neck.", naming="ms"):
+    """graphs.RPN parameters under the reference's names (MindSpore, or the det3d torch original with naming='torch')."""
+    bn_names = ("gamma", "beta", "moving_mean", "moving_variance") if naming == "ms" else ("weight", "bias", "running_mean", "running_var")
+    out = {}
+    for m, conv, bn in _rpn_slots(model, prefix):
+        out[conv + ".weight"] = m.weight_t if hasattr(m, "weight_t") else m.weight
+        for n, v in zip(bn_names, m.bn[:4]):
+            out[f"{bn}.{n}"] = v
+    return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()}
+
+
+def load_rpn(model, params, prefix="neck.", naming="auto", strict=True):
+    """Write a CenterPoint / PointPillars checkpoint's neck into a graphs.RPN; returns the unused keys.  naming 'torch' goes
+    through `torch_to_ms_generic` first; call model.to(device) afterwards to fold / pack."""
+    if naming == "auto":
+        naming = "torch" if any(k.endswith("running_var") for k in params) else "ms"
+    if naming == "torch":
+        kmap = torch_to_ms_generic(params.keys())
+        params = {kmap[k]: v for k, v in params.items() if k in kmap}
+    used = set()
+
+    def get(key, like):
+        if key not in params:
+            if strict:
+                raise KeyError(f"checkpoint has no {key!r}")
+            return None
+        a = np.asarray(params[key])
+        if tuple(a.shape) != tuple(like.shape):
+            raise ValueError(f"{key}: checkpoint shape {tuple(a.shape)} != model shape {tuple(like.shape)}")
+        used.add(key)
+        return torch.from_numpy(a.astype(np.float32))
+
+    for m, conv, bn in _rpn_slots(model, prefix):
+        attr = "weight_t" if hasattr(m, "weight_t") else "weight"
+        w = get(conv + ".weight", getattr(m, attr))
+        if w is not None:
+            setattr(m, attr, w)
+        vals = [get(f"{bn}.{n}", m.bn[i]) for i, n in enumerate(("gamma", "beta", "moving_mean", "moving_variance"))]
+        if all(v is not None for v in vals):
+            m.bn = (vals[0], vals[1], vals[2], vals[3], m.bn[4])
+    return sorted(k for k in params if k not in used)

@@ -78,3 +78,62 @@ def test_shape_mismatch_and_missing_keys_are_errors(tmp_path):
     except KeyError:
         pass
     assert weights.load_centernet(_model(2), st, strict=False) == []
+
+
+# ----------------------------------------------------------------------------- CenterPoint / PointPillars
+def _convert_procedure(keys):
+    """The loop of centerpoint/det3d_ms/models/detectors/point_pillars.py:137-168 restated on key names only."""
+    keys = sorted(keys)
+    out = []
+    for item in keys:
+        if "num_batches_tracked" in item or "global_step" in item:
+            continue
+        if "running_mean" in item:
+            out.append((item, item.replace("running_mean", "moving_mean")))
+        elif "running_var" in item:
+            out.append((item, item.replace("running_var", "moving_variance")))
+        elif "bias" in item:
+            out.append((item, item.replace("bias", "beta") if item.replace("bias", "running_var") in keys else item))
+        elif "weight" in item:
+            out.append((item, item.replace("weight", "gamma") if item.replace("weight", "running_var") in keys else item))
+        else:
+            out.append((item, item))
+    return dict(out)
+
+
+def test_centerpoint_key_rule():
+    rpn = graphs.RPN(layer_nums=(1, 1), ds_layer_strides=(2, 2), ds_num_filters=(16, 32), us_layer_strides=(1, 2),
+                     us_num_filters=(16, 16), num_input_features=8, seed=3)
+    tk = list(weights.rpn_state(rpn, naming="torch")) + ["neck.blocks.0.2.num_batches_tracked", "global_step",
+                                                         "bbox_head.tasks.0.hm.1.weight", "bbox_head.tasks.0.hm.1.bias"]
+    kmap = weights.torch_to_ms_generic(tk)
+    assert kmap == _convert_procedure(tk)
+    assert set(kmap.values()) - {"bbox_head.tasks.0.hm.1.weight", "bbox_head.tasks.0.hm.1.bias"} == set(weights.rpn_state(rpn, naming="ms"))
+    # the cell indices of rpn.py:114-143 / :60-105
+    ms = weights.rpn_state(rpn, naming="ms")
+    assert ms["neck.blocks.0.1.weight"].shape == (16, 8, 3, 3) and ms["neck.blocks.0.4.weight"].shape == (16, 16, 3, 3)
+    assert ms["neck.blocks.1.2.gamma"].shape == (32,) and ms["neck.deblocks.0.0.weight"].shape == (16, 16, 1, 1)
+    assert ms["neck.deblocks.1.0.weight"].shape == (32, 16, 2, 2)     # Conv2dTranspose: [Cin, Cout, k, k]
+
+
+def test_rpn_checkpoint_round_trip_both_namings(tmp_path):
+    kw = dict(layer_nums=(1, 2), ds_layer_strides=(2, 2), ds_num_filters=(16, 32), us_layer_strides=(1, 2),
+              us_num_filters=(16, 16), num_input_features=8)
+    a, b, c = graphs.RPN(seed=1, **kw), graphs.RPN(seed=2, **kw), graphs.RPN(seed=3, **kw)
+    p = str(tmp_path / "cp.ckpt")
+    weights.write_ms_ckpt(p, weights.rpn_state(a, naming="ms"))
+    assert weights.load_rpn(b, weights.read_ms_ckpt(p)) == []
+    q = str(tmp_path / "cp.pth")
+    sd = {k: torch.from_numpy(v) for k, v in weights.rpn_state(a, naming="torch").items()}
+    sd["neck.blocks.0.2.num_batches_tracked"] = torch.tensor(7)
+    torch.save({"state_dict": sd}, q)
+    assert weights.load_rpn(c, weights.read_torch_pth(q)) == []
+    sa = weights.rpn_state(a)
+    for m in (b, c):
+        sm = weights.rpn_state(m)
+        assert all(np.array_equal(sa[k], sm[k]) for k in sa)
+
+
+def test_pointpillars_train_checkpoint_prefixes():
+    p = {"network.network.rpn.blocks.0.1.weight": 1, "optimizer.rpn.blocks.0.2.gamma": 2, "global_step": 3, "learning_rate": 4}
+    assert weights.strip_net_prefix(p) == {"rpn.blocks.0.1.weight": 1, "rpn.blocks.0.2.gamma": 2}
