@@ -150,6 +150,12 @@ typedef struct md_conv2d_attrs {
     int32_t korder;              /* K order of the packed weights: 0 = (kh,kw,ci) [default]; 1 = (ci/64, kh,kw, ci%64)
                                     (needs Cin % 64 == 0): taps innermost, so consecutive K tiles of a 3x3 window
                                     re-read nearly the same activation lines */
+    /* channel-slice operands (all zero = whole tensors), so that split / concat graphs (C2f, C3: chunk -> bottlenecks ->
+     * concat) need no copies: every branch reads and writes its channel range of ONE concat buffer. */
+    int32_t x_c_off, x_cin;      /* x_cin > 0: the conv reads channels [x_c_off, x_c_off + x_cin) of x[N,H,W,C] (both % 8 == 0;
+                                    the packed weights are for Cin = x_cin) */
+    int32_t res_slice, res_c_off;/* res_slice != 0: residual is [N,Ho,Wo,R] and channels [res_c_off, res_c_off + Cout) are added
+                                    (res_c_off % 8 == 0; unit output stride, no res_upsample) */
 } md_conv2d_attrs;
 /* Replaces Conv2d -> BatchNorm2d(eval) -> [+ residual] -> ReLU of the reference graphs
  * (centernet/src/resnet.py:109-178,181-252; centerpoint/det3d_ms/models/necks/rpn.py:9-154).

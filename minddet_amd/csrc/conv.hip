@@ -68,6 +68,10 @@ struct ConvArgs {
     int stamp;              // diagnostic (variant 25): a mid-grid workgroup overwrites the first output bytes with s_memtime stamps
     int res_up;             // 1: residual is [N, ceil(Ho/2), ceil(Wo/2), Cout], read with nearest 2x upsampling
                             //    (the FPN top-down add fused into the lateral 1x1 conv); plain addressing only
+    int Xs;                 // pixel stride of x in channels (== Cin unless the input is a channel slice of a wider tensor;
+                            // a.x then already points at the slice's first channel)
+    int Rs;                 // 0: the residual has the output's layout; > 0: residual pixel m, channel c at m*Rs + c (a channel
+                            // slice of a wider [N,Ho,Wo,Rs] tensor, a.res pointing at its first channel)
 };
 
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((unsigned)v << 16); }
@@ -178,14 +182,14 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         if (MODE == 2 && a.pointwise) {
             // 1x1 / stride 1 / pad 0: input pixel == output pixel, no (n, ho, wo) decode (two integer divisions per row:
             // on the short-K layers this setup cost as many VALU cycles as the whole K loop)
-            if (m < a.M) { p_base[i] = m * a.Cin * 2 + chunk * 16; p_taps[i] = 1u; }
+            if (m < a.M) { p_base[i] = m * a.Xs * 2 + chunk * 16; p_taps[i] = 1u; }
         } else if (m < a.M) {
             const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
             const int ho = r / a.Wo, wo = r - ho * a.Wo;
             const int hi0 = ho * a.stride - a.pad_top, wi0 = wo * a.stride - a.pad_left;
             p_hw0[i] = (hi0 << 16) | (wi0 & 0xffff);
             if constexpr (MODE == 0) p_base[i] = n * a.H * a.W;
-            else p_base[i] = (((n * a.H + hi0) * a.W + wi0) * a.Cin) * 2 + (MODE == 2 ? chunk * 16 : 0);
+            else p_base[i] = (((n * a.H + hi0) * a.W + wi0) * a.Xs) * 2 + (MODE == 2 ? chunk * 16 : 0);
             if constexpr (MODE == 2) {
                 unsigned bits = 0u, bit = 1u;
                 for (int dy = 0; dy < a.kh; ++dy)
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
             const int hi = (p_hw0[i] >> 16) + q_kh, wi = (int)(short)(p_hw0[i] & 0xffff) + q_kw;
             const bool ok = q_tap < n_taps && p_base[i] >= 0 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) v = *reinterpret_cast<const u32x4 *>(a.x + ((size_t)(p_base[i] + hi * a.W + wi)) * a.Cin + q_cc * 8);
+            if (ok) v = *reinterpret_cast<const u32x4 *>(a.x + ((size_t)(p_base[i] + hi * a.W + wi)) * a.Xs + q_cc * 8);
             rb[GLDS ? 0 : i] = v;
         }
         advance_k();
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(A + (wrow + RPP * i) * ROWB), 16,
                                                      a_off0 + i * (RPP * a.Kpad * 2), kt * (BK * 2), 0, 0);
         if constexpr (MODE == 2) {
-            const int soff = ((s_kh * a.W + s_kw) * a.Cin + s_cc0 * 8) * 2;
+            const int soff = ((s_kh * a.W + s_kw) * a.Xs + s_cc0 * 8) * 2;
 #pragma unroll
             for (int i = 0; i < B_ROWS; ++i) {
                 const unsigned voff = ((p_taps[i] >> s_tap) & 1u) ? (unsigned)(p_base[i] + soff) : OOR;
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
                 if (s_tap == n_taps) { s_tap = 0; s_kh = 0; s_kw = 0; s_cc0 += 8; }
             }
         } else {
-            const int tapoff = ((q_kh * a.W + q_kw) * a.Cin + q_cc * 8) * 2;
+            const int tapoff = ((q_kh * a.W + q_kw) * a.Xs + q_cc * 8) * 2;
 #pragma unroll
             for (int i = 0; i < B_ROWS; ++i) {
                 const int hi = (p_hw0[i] >> 16) + q_kh, wi = (int)(short)(p_hw0[i] & 0xffff) + q_kw;
@@ -433,7 +437,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
             const int p_local = e / CPP, cc = e % CPP;
             const int m = pix0 + p_local, c = cout0 + cc * 8;
             rres[it] = (u32x4){0u, 0u, 0u, 0u};
-            if (m < a.M && c < a.Cout) rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + out_offset(m, c)));
+            if (m < a.M && c < a.Cout)
+                rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + (GEN && a.Rs ? (size_t)m * a.Rs + c : out_offset(m, c))));
         }
     }
     // bias (+ReLU when no residual) -> bf16x4 -> LDS [pixel][cout] image
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
 
 template <int NT, int WC, int WP, int FC, int FP, int MODE, int MF = 0>
 static int launch_conv(ConvArgs &a, hipStream_t s) {
-    const bool plain = MODE == 2 && MF == 0 && !a.adv && !a.res_up && a.relu != 2;
+    const bool plain = MODE == 2 && MF == 0 && !a.adv && !a.res_up && a.relu != 2 && !a.Rs;
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
     g_last_kernel = MODE == 1 ? MD_CONV_KERNEL_IGEMM_GENERIC_K : (CT == 128 && PT == 128 ? MD_CONV_KERNEL_IGEMM_128 :
                     (CT < 128 ? MD_CONV_KERNEL_IGEMM_SMALL_COUT : MD_CONV_KERNEL_OTHER));
@@ -605,7 +610,7 @@ __global__ __launch_bounds__(256, CT == 64 ? 4 : 2) void conv3x3_halo_kernel(Con
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         const int lchunk = (lane & 7) ^ ((r >> 1) & 7);
         const bool ok = q < HALO_DMAS && r < HALO_ROWS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        h_off[j] = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + lchunk * 8) * 2) : OOR;
+        h_off[j] = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Xs + lchunk * 8) * 2) : OOR;
     }
     const int n_chunks = a.Cin / 64;
     auto dma_weights = [&](int step, int buf) {
@@ -686,17 +691,17 @@ __global__ __launch_bounds__(256, CT == 64 ? 4 : 2) void conv3x3_halo_kernel(Con
 
     // ---- epilogue (same scheme as conv_igemm_kernel): bias -> bf16x4 -> LDS [pixel][cout] -> 16-B NHWC stores
     constexpr int CPP = CT / 8, EP_ITERS = PT * CPP / 256;
-    auto pix_off = [&](int p_local, int cglob) -> long long {
+    auto pix_off = [&](int p_local, int cglob, int cstride) -> long long {
         const int y = y0 + (p_local >> 4), x = x0 + (p_local & 15);
         if (y >= a.H || x >= a.W || cglob >= a.Cout) return -1;
-        return ((long long)(n * a.H + y) * a.W + x) * a.Cout + cglob;
+        return ((long long)(n * a.H + y) * a.W + x) * cstride + cglob;
     };
     u32x4 rres[EP_ITERS];
     if (a.res) {
 #pragma unroll
         for (int it = 0; it < EP_ITERS; ++it) {
             const int e = tid + it * 256;
-            const long long off = pix_off(e / CPP, cout0 + (e % CPP) * 8);
+            const long long off = pix_off(e / CPP, cout0 + (e % CPP) * 8, a.Rs ? a.Rs : a.Cout);
             rres[it] = (u32x4){0u, 0u, 0u, 0u};
             if (off >= 0) rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + off));
         }
@@ -730,7 +735,7 @@ __global__ __launch_bounds__(256, CT == 64 ? 4 : 2) void conv3x3_halo_kernel(Con
     for (int it = 0; it < EP_ITERS; ++it) {
         const int e = tid + it * 256;
         const int p_local = e / CPP, cc = e % CPP;
-        const long long off = pix_off(p_local, cout0 + cc * 8);
+        const long long off = pix_off(p_local, cout0 + cc * 8, a.Cout);
         if (off < 0) continue;
         u32x4 v = *reinterpret_cast<const u32x4 *>(E + p_local * EP_STRIDE + cc * 16);
         if (a.res) {
@@ -830,12 +835,12 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         const int m = pix0 + (i * 2 + (wave >> 2)) * 64 + hB * 32 + (wave & 3) * 8 + (lane >> 3);
         p_base[q] = 0; p_taps[q] = 0u;
         if (a.pointwise) {
-            if (m < a.M) { p_base[q] = m * a.Cin * 2 + chunk * 16; p_taps[q] = 1u; }
+            if (m < a.M) { p_base[q] = m * a.Xs * 2 + chunk * 16; p_taps[q] = 1u; }
         } else if (m < a.M) {
             const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
             const int ho = r / a.Wo, wo = r - ho * a.Wo;
             const int hi0 = ho * a.stride - a.pad_top, wi0 = wo * a.stride - a.pad_left;
-            p_base[q] = (((n * a.H + hi0) * a.W + wi0) * a.Cin) * 2 + chunk * 16;
+            p_base[q] = (((n * a.H + hi0) * a.W + wi0) * a.Xs) * 2 + chunk * 16;
             unsigned bits = 0u, bit = 1u;
             for (int dy = 0; dy < a.kh; ++dy)
                 for (int dx = 0; dx < a.kw; ++dx, bit <<= 1)
@@ -870,7 +875,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         if (ABL == 1 && kt >= 2) return;
         char *dst = smem + ((kt & 1) * 4 + hbuf) * PP_HALF + wave * (8 * ROWB);
         const unsigned dead = (unsigned)((nk - 1 - kt) >> 31) << 31;
-        const int soff = ((w.kh * a.W + w.kw) * a.Cin + w.cc0 * 8) * 2;
+        const int soff = ((w.kh * a.W + w.kw) * a.Xs + w.cc0 * 8) * 2;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const unsigned voff = ((p_taps[hB * 2 + i] >> (w.tap & 31)) & 1u) ? ((unsigned)(p_base[hB * 2 + i] + soff) | dead) : OOR;
@@ -1103,6 +1108,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         return (((size_t)n * a.Hf + ho * a.os + a.oy) * a.Wf + wo * a.os + a.ox) * a.Ctot + a.c_off + c;
     };
     auto res_offset = [&](int m, int c) -> size_t {
+        if (GEN && a.Rs) return (size_t)m * a.Rs + c;
         if (!(GEN && a.res_up)) return out_offset(m, c);
         const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
         const int ho = r / a.Wo, wo = r - ho * a.Wo;
@@ -1176,7 +1182,7 @@ static int launch_conv_pingpong(ConvArgs &a, hipStream_t s) {
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
     const int lds = 256 * (256 * 2 + 16) + 256 * 4;  // 136,192 B: the epilogue image (>= the 128 KiB of staging buffers) + bias
     constexpr bool HAS_PLAIN = (ABL == 0 || ABL == 4) && MF == 0;
-    const bool plain = HAS_PLAIN && !a.adv && !a.res_up && a.relu != 2;
+    const bool plain = HAS_PLAIN && !a.adv && !a.res_up && a.relu != 2 && !a.Rs;
     auto k = plain ? conv_pingpong_kernel<ABL, MF, !HAS_PLAIN> : conv_pingpong_kernel<ABL, MF, true>;
     if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, s, a);
@@ -1251,6 +1257,14 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     a.res = (const uint16_t *)params[3];
     a.y = (uint16_t *)params[4];
     a.N = (int)shapes[0][0]; a.H = (int)shapes[0][1]; a.W = (int)shapes[0][2]; a.Cin = (int)shapes[0][3];
+    // channel-slice operands: x = channels [x_c_off, x_c_off + x_cin) of the [N,H,W,Xs] tensor; residual = channels
+    // [res_c_off, res_c_off + Cout) of a [N,Ho,Wo,Rs] tensor (res_slice)
+    a.Xs = a.Cin; a.Rs = 0;
+    if (at->x_cin > 0) {
+        if (at->x_c_off < 0 || at->x_c_off % 8 || at->x_cin % 8 || at->x_c_off + at->x_cin > a.Xs) return MD_ERR_ARG;
+        a.Cin = at->x_cin;
+        if (a.x) a.x += at->x_c_off;
+    } else if (at->x_c_off != 0) return MD_ERR_ARG;
     a.Hf = (int)shapes[4][1]; a.Wf = (int)shapes[4][2]; a.Ctot = (int)shapes[4][3];
     a.kh = at->kh; a.kw = at->kw; a.stride = at->stride; a.pad = at->pad; a.relu = at->relu;
     if (a.kh < 1 || a.kw < 1 || a.stride < 1 || a.pad < 0 || a.relu < 0 || a.relu > 2) return MD_ERR_ARG;
@@ -1285,7 +1299,14 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     const int cout_pad = (a.Cout + ctile - 1) / ctile * ctile;
     if (a.Kpad % BK || a.Kpad < a.Kreal || shapes[1][0] != cout_pad) return MD_ERR_ARG;
     if (numel(ndims, shapes, 2) != cout_pad) return MD_ERR_ARG;
-    if (params[3] && !a.res_up && (ndims[3] != 4 || numel(ndims, shapes, 3) != numel(ndims, shapes, 4))) return MD_ERR_ARG;
+    if (at->res_slice) {
+        if (!params[3] || a.res_up || ndims[3] != 4 || shapes[3][0] != a.N || shapes[3][1] != a.Ho || shapes[3][2] != a.Wo ||
+            a.os != 1 || a.oy || a.ox || a.Ho != a.Hf || a.Wo != a.Wf || at->res_c_off < 0 || at->res_c_off % 8 ||
+            at->res_c_off + a.Cout > shapes[3][3])
+            return MD_ERR_ARG;
+        a.Rs = (int)shapes[3][3];
+        a.res += at->res_c_off;
+    } else if (params[3] && !a.res_up && (ndims[3] != 4 || numel(ndims, shapes, 3) != numel(ndims, shapes, 4))) return MD_ERR_ARG;
     if (a.res_up && (ndims[3] != 4 || shapes[3][0] != a.N || shapes[3][1] != (a.Ho + 1) / 2 || shapes[3][2] != (a.Wo + 1) / 2 ||
                      shapes[3][3] != a.Cout))
         return MD_ERR_ARG;
@@ -1303,7 +1324,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     // 17-19 = ping-pong timing ablations / stamps (wrong results); 20 = LDS-DMA 128x128 with one staging buffer;
     // 25 = 20 + stamps; 27 = 64-cout halo kernel
     int variant = variant_override >= 0 ? variant_override : at->variant;
-    const long long x_bytes = (long long)a.N * a.H * a.W * a.Cin * 2, w_bytes = (long long)cout_pad * a.Kpad * 2;
+    const long long x_bytes = (long long)a.N * a.H * a.W * a.Xs * 2 - (at->x_cin > 0 ? at->x_c_off * 2 : 0), w_bytes = (long long)cout_pad * a.Kpad * 2;
     const bool dma_ok = x_bytes < 0x7fff0000LL && w_bytes < 0x7fff0000LL;  // 32-bit DMA offsets, out-of-range marker 2^31
     a.x_bytes = (unsigned)(dma_ok ? x_bytes : 0);
     a.w_bytes = (unsigned)(dma_ok ? w_bytes : 0);

@@ -59,11 +59,24 @@ class ConvModule:
                                        relu=self.act).to(device)
         return self
 
-    def __call__(self, x, residual=None, out=None, c_off=0):
-        return nn_ops.conv2d(x, self.packed, residual=residual, out=out, c_off=c_off)
+    def __call__(self, x, residual=None, out=None, c_off=0, x_c_off=None, res_c_off=None):
+        return nn_ops.conv2d(x, self.packed, residual=residual, out=out, c_off=c_off, x_c_off=x_c_off, res_c_off=res_c_off)
 
     def macs(self, ho, wo):
         return ho * wo * self.cout * self.cin * self.k * self.k
+
+
+def merged_conv(mods, device):
+    """Several ConvModules that read the same input (same kernel / stride / pad / activation) as ONE md_conv2d launch whose
+    output channels are the modules' outputs side by side: the same arithmetic per output channel, the input read once."""
+    m0 = mods[0]
+    if any((m.cin, m.k, m.stride, m.pad, m.act, m.bn is None, m.bias is None) != (m0.cin, m0.k, m0.stride, m0.pad, m0.act, m0.bn is None, m0.bias is None)
+           for m in mods):
+        raise ValueError("merged_conv: the convs must share input, geometry and activation")
+    w = torch.cat([m.weight for m in mods], 0)
+    bn = None if m0.bn is None else tuple(torch.cat([torch.as_tensor(m.bn[i]) for m in mods]) for i in range(4)) + (m0.bn[4],)
+    bias = None if m0.bias is None else torch.cat([m.bias for m in mods])
+    return nn_ops.pack_conv(w, bias=bias, bn=bn, stride=m0.stride, pad=m0.pad, relu=m0.act).to(device)
 
 
 # ----------------------------------------------------------------------------- ResNet (centernet/src/resnet.py)
@@ -677,26 +690,26 @@ class C3:
         self.cv1, self.cv2, self.cv3 = _yconv(init, c1, c_), _yconv(init, c1, c_), _yconv(init, 2 * c_, c2)
         self.m = [(_yconv(init, c_, c_, 1), _yconv(init, c_, c_, 3)) for _ in range(n)]
         self.shortcut, self.c_ = shortcut, c_
+        self._cv12 = None
 
     def modules(self):
         return [self.cv1, self.cv2, self.cv3] + [m for pair in self.m for m in pair]
 
-    def __call__(self, x):
+    def __call__(self, x, x_c_off=None, out=None, c_off=0):
+        """No copies: one launch computes [cv1(x) | cv2(x)] into the concat buffer; every bottleneck then updates channels
+        [0, c_) in place (its 1x1 reads the slice, its 3x3 adds the slice as residual and writes it back: each element is read
+        and written by the same thread)."""
         n, h, w, _ = x.shape
-        cat = torch.empty((n, h, w, 2 * self.c_), dtype=torch.bfloat16, device=x.device)
-        y = self.cv1(x)
-        for i, (a, b) in enumerate(self.m):
-            last = i == len(self.m) - 1
+        if self._cv12 is None:
+            self._cv12 = merged_conv([self.cv1, self.cv2], x.device)
+        cat = nn_ops.conv2d(x, self._cv12, x_c_off=x_c_off)
+        for a, b in self.m:
+            t = a(cat, x_c_off=0)
             if self.shortcut:
-                y = b(a(y), residual=y)          # SiLU first, then the shortcut add (md_conv2d relu code 2)
-                if last:
-                    nn_ops.concat_copy(y, cat, 0)
-            elif last:
-                b(a(y), out=cat, c_off=0)        # no residual: the last 3x3 writes its concat slice in place
+                b(t, residual=cat, res_c_off=0, out=cat, c_off=0)     # SiLU first, then the shortcut add (md_conv2d relu code 2)
             else:
-                y = b(a(y))
-        self.cv2(x, out=cat, c_off=self.c_)
-        return self.cv3(cat)
+                b(t, out=cat, c_off=0)
+        return self.cv3(cat, out=out, c_off=c_off)
 
 
 class SPPF:
@@ -768,21 +781,24 @@ class YOLOv5:
         return self
 
     def features(self, x):
-        x = self.b2(self.b1(self.b0(x)))
-        p3 = self.b4(self.b3(x))
-        p4 = self.b6(self.b5(p3))
-        x = self.b9(self.b8(self.b7(p4)))
+        x = self.b3(self.b2(self.b1(self.b0(x))))
+        # p3 / p4 are produced straight into the second half of the PAN concat buffers that consume them later
+        # ([upsampled top | skip]); the next backbone conv reads them as a channel slice
+        n, h, w, _ = x.shape
+        c = self.b4.cv3.cout
+        cat17 = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=x.device)
+        self.b4(x, out=cat17, c_off=c)
+        x = self.b5(cat17, x_c_off=c)
+        n, h, w, _ = x.shape
+        c = self.b6.cv3.cout
+        cat13 = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=x.device)
+        self.b6(x, out=cat13, c_off=c)
+        x = self.b9(self.b8(self.b7(cat13, x_c_off=c)))
         h10 = self.h10(x)
-        n, h, w, c = p4.shape
-        cat = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=x.device)
-        nn_ops.upsample2x(h10, cat, 0)
-        nn_ops.concat_copy(p4, cat, c)
-        h14 = self.h14(self.h13(cat))
-        n, h, w, c = p3.shape
-        cat = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=x.device)
-        nn_ops.upsample2x(h14, cat, 0)
-        nn_ops.concat_copy(p3, cat, c)
-        o3 = self.h17(cat)
+        nn_ops.upsample2x(h10, cat13, 0)
+        h14 = self.h14(self.h13(cat13))
+        nn_ops.upsample2x(h14, cat17, 0)
+        o3 = self.h17(cat17)
         n, h, w, c = h14.shape
         cat = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=x.device)
         self.h18(o3, out=cat, c_off=0)
@@ -835,26 +851,27 @@ class C2f:
         self.cv1a, self.cv1b = _yconv(init, c1, c, 1), _yconv(init, c1, c, 1)
         self.cv2 = _yconv(init, (2 + n) * c, c2, 1)
         self.m = [(_yconv(init, c, c, 3), _yconv(init, c, c, 3)) for _ in range(n)]
+        self._cv1 = None
 
     def modules(self):
         return [self.cv1a, self.cv1b, self.cv2] + [m for pair in self.m for m in pair]
 
-    def __call__(self, x):
+    def __call__(self, x, x_c_off=None, out=None, c_off=0):
+        """No copies: one launch writes (y0 | y1) = cv1(x) into channels [0, 2c) of the concat buffer; bottleneck i reads its
+        input (and its shortcut) as channels [(1+i)c, (2+i)c) of that buffer and writes [(2+i)c, (3+i)c)."""
         n, h, w, _ = x.shape
-        cat = torch.empty((n, h, w, (2 + self.n) * self.c), dtype=torch.bfloat16, device=x.device)
-        self.cv1a(x, out=cat, c_off=0)
-        y = self.cv1b(x)
-        nn_ops.concat_copy(y, cat, self.c)
+        c = self.c
+        if self._cv1 is None:
+            self._cv1 = merged_conv([self.cv1a, self.cv1b], x.device)
+        cat = torch.empty((n, h, w, (2 + self.n) * c), dtype=torch.bfloat16, device=x.device)
+        nn_ops.conv2d(x, self._cv1, out=cat, c_off=0, x_c_off=x_c_off)
         for i, (a, b) in enumerate(self.m):
+            t = a(cat, x_c_off=(1 + i) * c)
             if self.shortcut:
-                y = b(a(y), residual=y)          # SiLU first, then the shortcut add
-                nn_ops.concat_copy(y, cat, (2 + i) * self.c)
-            elif i == len(self.m) - 1:
-                b(a(y), out=cat, c_off=(2 + i) * self.c)
+                b(t, residual=cat, res_c_off=(1 + i) * c, out=cat, c_off=(2 + i) * c)   # SiLU first, then the shortcut add
             else:
-                y = b(a(y))
-                nn_ops.concat_copy(y, cat, (2 + i) * self.c)
-        return self.cv2(cat)
+                b(t, out=cat, c_off=(2 + i) * c)
+        return self.cv2(cat, out=out, c_off=c_off)
 
 
 @DETECTORS.register_module
@@ -898,6 +915,7 @@ class YOLOv8:
         self.strides = (8, 16, 32)
         self.conf_thres, self.iou_thres, self.max_det, self.nms_pre = conf_thres, iou_thres, max_det, nms_pre
         self._seg = {}
+        self._stem2 = {}
 
     def conv_modules(self):
         out = [self.b0, self.b1, self.b3, self.b5, self.b7, self.h16, self.h19]
@@ -912,22 +930,24 @@ class YOLOv8:
             m.to(device)
         return self
 
-    @staticmethod
-    def _up_cat(top, skip):
-        n, h, w, c = skip.shape
-        ct = top.shape[3]
-        cat = torch.empty((n, h, w, ct + c), dtype=torch.bfloat16, device=skip.device)
-        nn_ops.upsample2x(top, cat, 0)
-        nn_ops.concat_copy(skip, cat, ct)
-        return cat
-
     def features(self, x):
-        x = self.b2(self.b1(self.b0(x)))
-        p3 = self.b4(self.b3(x))
-        p4 = self.b6(self.b5(p3))
-        p5 = self.b9(self.b8(self.b7(p4)))
-        h12 = self.h12(self._up_cat(p5, p4))
-        o3 = self.h15(self._up_cat(h12, p3))
+        x = self.b3(self.b2(self.b1(self.b0(x))))
+        # p3 / p4 are produced straight into the PAN concat buffers that consume them later ([upsampled top | skip]); the next
+        # backbone conv reads them as a channel slice
+        n, h, w, _ = x.shape
+        c_top = self.h12.cv2.cout
+        cat15 = torch.empty((n, h, w, c_top + self.b4.cv2.cout), dtype=torch.bfloat16, device=x.device)
+        self.b4(x, out=cat15, c_off=c_top)
+        x = self.b5(cat15, x_c_off=c_top)
+        n, h, w, _ = x.shape
+        c_top = self.b9.cv2.cout
+        cat12 = torch.empty((n, h, w, c_top + self.b6.cv2.cout), dtype=torch.bfloat16, device=x.device)
+        self.b6(x, out=cat12, c_off=c_top)
+        p5 = self.b9(self.b8(self.b7(cat12, x_c_off=c_top)))
+        nn_ops.upsample2x(p5, cat12, 0)
+        h12 = self.h12(cat12)
+        nn_ops.upsample2x(h12, cat15, 0)
+        o3 = self.h15(cat15)
         n, h, w, c = h12.shape
         cat = torch.empty((n, h, w, o3.shape[3] + c), dtype=torch.bfloat16, device=x.device)
         self.h16(o3, out=cat, c_off=0)
@@ -942,8 +962,12 @@ class YOLOv8:
         for f, bx, cl in zip((o3, o4, o5), self.box, self.cls):
             n, h, w, _ = f.shape
             head = torch.zeros((n, h, w, self.head_c), dtype=torch.bfloat16, device=f.device)
-            bx[2](bx[1](bx[0](f)), out=head, c_off=0)                       # 4 * reg_max distribution logits
-            cl[2](cl[1](cl[0](f)), out=head, c_off=4 * self.reg_max)        # class logits
+            key = id(bx[0])
+            if key not in self._stem2:                                      # the two branch stems read f once: one launch
+                self._stem2[key] = merged_conv([bx[0], cl[0]], f.device)
+            t = nn_ops.conv2d(f, self._stem2[key])
+            bx[2](bx[1](t, x_c_off=0), out=head, c_off=0)                   # 4 * reg_max distribution logits
+            cl[2](cl[1](t, x_c_off=bx[0].cout), out=head, c_off=4 * self.reg_max)   # class logits
             heads.append(head)
         return heads
 

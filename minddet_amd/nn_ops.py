@@ -18,7 +18,8 @@ class _ConvAttrs(ctypes.Structure):
                 ("relu", ctypes.c_int32), ("variant", ctypes.c_int32), ("adv", ctypes.c_int32), ("pad_top", ctypes.c_int32),
                 ("pad_left", ctypes.c_int32), ("sub_h", ctypes.c_int32), ("sub_w", ctypes.c_int32),
                 ("out_stride", ctypes.c_int32), ("out_off_y", ctypes.c_int32), ("out_off_x", ctypes.c_int32),
-                ("c_off", ctypes.c_int32), ("cout", ctypes.c_int32), ("res_upsample", ctypes.c_int32), ("korder", ctypes.c_int32)]
+                ("c_off", ctypes.c_int32), ("cout", ctypes.c_int32), ("res_upsample", ctypes.c_int32), ("korder", ctypes.c_int32),
+                ("x_c_off", ctypes.c_int32), ("x_cin", ctypes.c_int32), ("res_slice", ctypes.c_int32), ("res_c_off", ctypes.c_int32)]
 
 
 def cout_tile(cout):
@@ -95,12 +96,13 @@ def conv_out_hw(h, w, pc):
 CONV_VARIANT = 0  # 0 auto; 1/2/3 force a kernel variant (A/B measurements, see md_conv2d_attrs)
 
 
-def conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0, res_upsample=False):
+def conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0, res_upsample=False, x_c_off=None, res_c_off=None):
     """x [N,H,W,Cin] bf16 NHWC contiguous CUDA tensor -> y [N,Ho,Wo,Cout] bf16.
     With `out` wider than the layer (channel concat, rpn.py:152) the result goes to channels
-    [c_off, c_off + Cout) of `out`."""
+    [c_off, c_off + Cout) of `out`.  x_c_off: the layer reads channels [x_c_off, x_c_off + pc.cin) of a wider x;
+    res_c_off: the residual is channels [res_c_off, res_c_off + Cout) of a wider [N,Ho,Wo,R] tensor."""
     n, h, w, c = x.shape
-    if c != pc.cin:
+    if x_c_off is None and c != pc.cin:
         raise _lib.MindDetHipError(f"conv2d: input has {c} channels, layer packed for {pc.cin}")
     ho, wo = conv_out_hw(h, w, pc)
     if out is None:
@@ -109,6 +111,10 @@ def conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0, res
                        int(CONV_VARIANT if variant is None else variant))
     attrs.korder = getattr(pc, "korder", 0)
     attrs.res_upsample = int(bool(res_upsample))
+    if x_c_off is not None:
+        attrs.x_c_off, attrs.x_cin = int(x_c_off), pc.cin
+    if res_c_off is not None:
+        attrs.res_slice, attrs.res_c_off = 1, int(res_c_off)
     if out.shape[3] != pc.cout or c_off:
         attrs.adv, attrs.pad_top, attrs.pad_left, attrs.sub_h, attrs.sub_w = 1, pc.pad, pc.pad, ho, wo
         attrs.out_stride, attrs.c_off, attrs.cout = 1, int(c_off), pc.cout

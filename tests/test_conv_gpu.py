@@ -242,3 +242,57 @@ def test_conv2d_head_batch_chunking_is_bit_identical():
     torch.cuda.synchronize()
     assert torch.equal(y0[:2], y1[:2])
     assert (y0[2].float() - y1[2].float()).abs().max().item() <= 2e-2 * (1 + y0[2].float().abs().max().item())
+
+
+@pytest.mark.parametrize("cfg", [
+    # name, N, H, W, Cin, Cout, k, act, x buffer channels, x offset, residual buffer channels, residual offset, output offset
+    ("igemm_1x1_silu", 2, 40, 40, 128, 128, 1, "silu", 320, 64, 256, 128, 128),
+    ("halo64_3x3_relu", 2, 33, 47, 64, 64, 3, "relu", 192, 128, 128, 64, 0),
+    ("pingpong_3x3_silu", 2, 128, 130, 256, 256, 3, "silu", 512, 256, 768, 512, 256),
+    ("igemm_3x3_silu", 1, 37, 53, 128, 128, 3, "silu", 256, 8, 136, 8, 0),
+    ("igemm_plain_3x3_relu_x_only", 1, 37, 53, 128, 128, 3, "relu", 256, 128, 0, 0, 0),
+    ("generic_k_8ch", 1, 20, 24, 8, 32, 3, "relu", 24, 16, 64, 32, 0),
+], ids=lambda c: c[0])
+def test_conv_channel_slice_operands_are_bit_identical(cfg):
+    """md_conv2d_attrs.x_c_off / res_c_off: a conv reading its input and its residual as channel ranges of wider tensors (the
+    split / concat graphs of C2f / C3 without copies) equals the same conv on contiguous copies of the ranges, bit for bit."""
+    from minddet_amd import nn_ops
+
+    name, N, H, W, Cin, Cout, k, act, xc, xo, rc, ro, co = cfg
+    g = torch.Generator().manual_seed(len(name))
+    wt = torch.randn((Cout, Cin, k, k), generator=g) * (2.0 / (k * k * Cin)) ** 0.5
+    pc = nn_ops.pack_conv(wt, bias=torch.randn((Cout,), generator=g) * 0.1, stride=1, pad=k // 2, relu=act).to(DEV)
+    xbuf = torch.randn((N, H, W, xc), generator=g).to(torch.bfloat16).to(DEV)
+    rbuf = torch.randn((N, H, W, rc), generator=g).to(torch.bfloat16).to(DEV) if rc else None
+    x_c = xbuf[..., xo:xo + Cin].contiguous()
+    r_c = rbuf[..., ro:ro + Cout].contiguous() if rc else None
+    ref = nn_ops.conv2d(x_c, pc, residual=r_c)
+    got = nn_ops.conv2d(xbuf, pc, residual=rbuf, x_c_off=xo, res_c_off=ro if rc else None)
+    assert torch.equal(got, ref)
+    # and straight into a concat buffer
+    cat = torch.full((N, H, W, co + Cout + 8), 3.0, dtype=torch.bfloat16, device=DEV)
+    nn_ops.conv2d(xbuf, pc, residual=rbuf, x_c_off=xo, res_c_off=ro if rc else None, out=cat, c_off=co)
+    assert torch.equal(cat[..., co:co + Cout], ref) and (cat[..., co + Cout:] == 3.0).all() and (cat[..., :co] == 3.0).all()
+    # sanity against torch fp32 (the contiguous path itself is covered by test_conv_vs_torch_fp32)
+    y = F.conv2d(x_c.float().cpu().permute(0, 3, 1, 2), wt.to(torch.bfloat16).float(), pc.bias[:Cout].float().cpu(), padding=k // 2).permute(0, 2, 3, 1)
+    y = F.silu(y) if act == "silu" else y
+    if rc:
+        y = y.to(torch.bfloat16).float() + r_c.float().cpu() if act == "silu" else y + r_c.float().cpu()
+    y = torch.relu(y) if act == "relu" else y
+    assert ((ref.float().cpu() - y).abs() <= 2e-2 * y.abs() + 2e-2).all()
+
+
+def test_conv_channel_slice_rejects_bad_ranges():
+    from minddet_amd import _lib, nn_ops
+
+    pc = nn_ops.pack_conv(torch.randn((64, 64, 1, 1)) * 0.1).to(DEV)
+    x = torch.zeros((1, 8, 8, 128), dtype=torch.bfloat16, device=DEV)
+    for off in (4, 72, -8):
+        with pytest.raises(_lib.MindDetHipError):
+            nn_ops.conv2d(x, pc, x_c_off=off)
+    r = torch.zeros((1, 8, 8, 96), dtype=torch.bfloat16, device=DEV)
+    for off in (4, 40):
+        with pytest.raises(_lib.MindDetHipError):
+            nn_ops.conv2d(x, pc, x_c_off=0, residual=r, res_c_off=off)
+    with pytest.raises(_lib.MindDetHipError):
+        nn_ops.conv2d(x, pc, x_c_off=0, residual=torch.zeros((1, 4, 4, 96), dtype=torch.bfloat16, device=DEV), res_c_off=0)
