@@ -88,14 +88,16 @@ def main():
     KNAMES = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<128x128>", 3: "conv_igemm_kernel<small cout>",
               4: "conv_igemm_kernel<generic K>", 5: "conv3x3_halo_kernel", 6: "conv variant"}
 
-    def timed_conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0, res_upsample=False):
+    def timed_conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0, res_upsample=False, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        y = orig_conv2d(x, pc, residual=residual, relu=relu, out=out, variant=variant, c_off=c_off, res_upsample=res_upsample)
+        y = orig_conv2d(x, pc, residual=residual, relu=relu, out=out, variant=variant, c_off=c_off, res_upsample=res_upsample, **kw)
         e1.record()
         n, ho, wo, _ = y.shape
-        byts = 2.0 * (x.numel() + n * ho * wo * pc.cout + pc.cout * pc.cin_real * pc.kh * pc.kw + (residual.numel() if residual is not None else 0))
-        records.append((e0, e1, 2.0 * n * ho * wo * pc.cout * pc.cin_real * pc.kh * pc.kw, tuple(x.shape), pc.cout, pc.kh, byts,
+        # algorithmic bytes: the channels the layer reads / writes (operands may be channel slices of wider tensors)
+        res_elems = 0 if residual is None else (residual.numel() if res_upsample else n * ho * wo * pc.cout)
+        byts = 2.0 * (x.shape[0] * x.shape[1] * x.shape[2] * pc.cin + n * ho * wo * pc.cout + pc.cout * pc.cin_real * pc.kh * pc.kw + res_elems)
+        records.append((e0, e1, 2.0 * n * ho * wo * pc.cout * pc.cin_real * pc.kh * pc.kw, tuple(x.shape[:3]) + (pc.cin,), pc.cout, pc.kh, byts,
                         last_kernel()))
         return y
 

@@ -735,8 +735,9 @@ __global__ __launch_bounds__(256, CT == 64 ? 4 : 2) void conv3x3_halo_kernel(Con
     for (int it = 0; it < EP_ITERS; ++it) {
         const int e = tid + it * 256;
         const int p_local = e / CPP, cc = e % CPP;
-        const long long off = pix_off(p_local, cout0 + cc * 8, a.Cout);
+        long long off = pix_off(p_local, cout0 + cc * 8, a.Ctot);   // concat output: channels [c_off, c_off + Cout) of Ctot
         if (off < 0) continue;
+        off += a.c_off;
         u32x4 v = *reinterpret_cast<const u32x4 *>(E + p_local * EP_STRIDE + cc * 16);
         if (a.res) {
             const u32x4 rv = rres[it];
@@ -1352,8 +1353,11 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     if (variant == 0 && pp_ok) return launch_conv_pingpong<0>(a, s);
     if (halo_ok && !a.res_up && variant == 11) return launch_conv3x3_halo<128, false>(a, s);  // superseded by the paths around it
     // 64-cout tiles of the halo kernel at four workgroups per CU (variant 27; auto for Cout <= 64)
-    const bool halo64_ok = dma_ok && !a.adv && a.korder == 1 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 &&
-                           a.Cin % 64 == 0 && a.Cout % 64 == 0 && cout_pad % 64 == 0 && !a.res_up;
+    // (a channel-concat output is fine: the kernel stores with the output tensor's channel stride; sub-pixel addressing is not)
+    const bool cat_only = !a.adv || (a.os == 1 && a.oy == 0 && a.ox == 0 && a.Ho == a.Hf && a.Wo == a.Wf && a.pad_top == a.pad &&
+                                     a.pad_left == a.pad && (!a.res || a.Rs));
+    const bool halo64_ok = dma_ok && cat_only && a.korder == 1 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 &&
+                           a.Cin % 64 == 0 && a.Cout % 64 == 0 && cout_pad % 64 == 0 && !a.res_up && a.Ho == a.H && a.Wo == a.W;
     if (halo64_ok && (variant == 27 || (variant == 0 && ctile == 64))) return launch_conv3x3_halo<64, true>(a, s);
     if (variant == 11) variant = 2;
     if (variant == 15 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0>(a, s);  // 256x256 ping-pong, 8 waves
