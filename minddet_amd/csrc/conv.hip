@@ -133,9 +133,11 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 
 // MF 0: v_mfma_f32_32x32x16_bf16 (FC x FP tiles of 32x32 per wave); MF 1: v_mfma_f32_16x16x32_bf16 (2FC x 2FP
 // tiles of 16x16, K 32 per instruction): same LDS traffic and cycles per flop, but the chip holds a higher
 // clock on the 16x16 shape under load (MI355X_MICROARCH.md, DVFS give-back item 7).
-// GEN false: the plain instantiation (no sub-pixel / concat addressing, no upsampled residual, no SiLU): the division-heavy
-// address code and the SiLU path of the general epilogue are compiled out (they were 2/3 of the kernel's instructions).
-template <int NT, int WC, int WP, int FC, int FP, int MODE, int MF = 0, bool GEN = true>
+// GEN 1: the general epilogue (sub-pixel output addressing, upsampled residual, any activation).  GEN 0 / 2: the plain
+// instantiations for ReLU-or-none / SiLU layers whose output is a whole tensor or a channel range of a concat buffer
+// (offset = m * Ctot + c_off + c): the division-heavy address code of the general epilogue is compiled out (it was 2/3 of the
+// kernel's instructions) and the activation is a compile-time choice.
+template <int NT, int WC, int WP, int FC, int FP, int MODE, int MF = 0, int GEN = 1>
 __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr bool GLDS = MODE != 0;
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
@@ -407,13 +409,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
     constexpr int CPP = CT / 8;                 // 16-B chunks per pixel row of the tile
     constexpr int EP_ITERS = PT * CPP / NT;     // chunks per thread
     auto out_offset = [&](int m, int c) -> size_t {
-        if (!(GEN && a.adv)) return (size_t)m * a.Cout + c;
+        if (!(GEN == 1 && a.adv)) return (size_t)m * a.Ctot + a.c_off + c;   // plain, or a channel-concat output
         const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
         const int ho = r / a.Wo, wo = r - ho * a.Wo;
         return (((size_t)n * a.Hf + ho * a.os + a.oy) * a.Wf + wo * a.os + a.ox) * a.Ctot + a.c_off + c;
     };
     u32x4 rres[EP_ITERS];
-    if (GEN && a.res_up) {
+    if (GEN == 1 && a.res_up) {
         // upsampled residual (FPN top-down add): (n, ho, wo) of the thread's first pixel by division, the following
         // pixels (NT / CPP apart) by carry -- two integer divisions per thread instead of two per 16-B chunk
         const int c = cout0 + (tid % CPP) * 8;
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
             const int m = pix0 + p_local, c = cout0 + cc * 8;
             rres[it] = (u32x4){0u, 0u, 0u, 0u};
             if (m < a.M && c < a.Cout)
-                rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + (GEN && a.Rs ? (size_t)m * a.Rs + c : out_offset(m, c))));
+                rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + (a.Rs ? (size_t)m * a.Rs + c : out_offset(m, c))));
         }
     }
     // bias (+ReLU when no residual) -> bf16x4 -> LDS [pixel][cout] image
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
                 float v0 = acc4[i][j][0] + bv.x, v1 = acc4[i][j][1] + bv.y, v2 = acc4[i][j][2] + bv.z, v3 = acc4[i][j][3] + bv.w;
                 if (a.relu == 1 && !a.res) {
                     v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                } else if (GEN && a.relu == 2) {
+                } else if (GEN == 2 || (GEN == 1 && a.relu == 2)) {
                     v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
                 }
                 uint2 pk;
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
                 // packed adds (v_pk_add_f32), one-instruction bf16 pack, ReLU on the packed pair: 8 VALU per 4 values
                 f32x2 s01 = (f32x2){acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
                 f32x2 s23 = (f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
-                if (GEN && a.relu == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
+                if (GEN == 2 || (GEN == 1 && a.relu == 2)) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
                 uint2 pk;
                 pk.x = pk_bf16(s01.x, s01.y);
                 pk.y = pk_bf16(s23.x, s23.y);
@@ -526,7 +528,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
 
 template <int NT, int WC, int WP, int FC, int FP, int MODE, int MF = 0>
 static int launch_conv(ConvArgs &a, hipStream_t s) {
-    const bool plain = MODE == 2 && MF == 0 && !a.adv && !a.res_up && a.relu != 2 && !a.Rs;
+    const bool cat_only = a.adv && a.os == 1 && !a.oy && !a.ox && a.Ho == a.Hf && a.Wo == a.Wf;
+    const bool plain = MODE == 2 && MF == 0 && (!a.adv || cat_only) && !a.res_up;
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
     g_last_kernel = MODE == 1 ? MD_CONV_KERNEL_IGEMM_GENERIC_K : (CT == 128 && PT == 128 ? MD_CONV_KERNEL_IGEMM_128 :
                     (CT < 128 ? MD_CONV_KERNEL_IGEMM_SMALL_COUT : MD_CONV_KERNEL_OTHER));
@@ -543,7 +546,9 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
     a.pt_per_xcd = (a.n_ptiles + 7) / 8;
     const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
-    auto k = plain ? conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, MF, !(MODE == 2 && MF == 0)> : conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, MF, true>;
+    constexpr bool HAS_PLAIN = MODE == 2 && MF == 0;
+    auto k = conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, MF, 1>;
+    if (plain) k = a.relu == 2 ? conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, MF, HAS_PLAIN ? 2 : 1> : conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, MF, HAS_PLAIN ? 0 : 1>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return MD_ERR_HIP;
@@ -797,7 +802,7 @@ struct KWalk { int tap, kh, kw, cc0; };
 
 // MF 0: v_mfma_f32_32x32x16_bf16, MF 1: v_mfma_f32_16x16x32_bf16 (same LDS image, reads and cycles per flop; the chip holds a
 // different clock on the two shapes under load -- MI355X_MICROARCH.md DVFS item 7 -- so both are built and the faster kept).
-template <int ABL, int MF = 0, bool GEN = true, bool HEAD = false>  // GEN as in conv_igemm_kernel; HEAD: fused 1x1 head; ABL 0: product; timing ablations (wrong results): 1 no in-loop staging, 2 no output stores, 4 stamps
+template <int ABL, int MF = 0, int GEN = 1, bool HEAD = false>  // GEN as in conv_igemm_kernel; HEAD: fused 1x1 head; ABL 0: product; timing ablations (wrong results): 1 no in-loop staging, 2 no output stores, 4 stamps
 __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     constexpr int CT = 256, PT = 256, NT = 512;
     constexpr int EP_STRIDE = CT * 2 + 16;
@@ -1044,7 +1049,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
                 float v0 = acc4[i][j][0] + bv.x, v1 = acc4[i][j][1] + bv.y, v2 = acc4[i][j][2] + bv.z, v3 = acc4[i][j][3] + bv.w;
                 if (a.relu == 1 && !a.res) {
                     v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                } else if (GEN && a.relu == 2) {
+                } else if (GEN == 2 || (GEN == 1 && a.relu == 2)) {
                     v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
                 }
                 uint2 pk;
@@ -1066,7 +1071,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
                 // packed adds (v_pk_add_f32), one-instruction bf16 pack, ReLU on the packed pair: 8 VALU per 4 values
                 f32x2 s01 = (f32x2){acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
                 f32x2 s23 = (f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
-                if (GEN && a.relu == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
+                if (GEN == 2 || (GEN == 1 && a.relu == 2)) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
                 uint2 pk;
                 pk.x = pk_bf16(s01.x, s01.y);
                 pk.y = pk_bf16(s23.x, s23.y);
@@ -1103,14 +1108,14 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         return;
     }
     auto out_offset = [&](int m, int c) -> size_t {
-        if (!(GEN && a.adv)) return (size_t)m * a.Cout + c;
+        if (!(GEN == 1 && a.adv)) return (size_t)m * a.Ctot + a.c_off + c;   // plain, or a channel-concat output
         const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
         const int ho = r / a.Wo, wo = r - ho * a.Wo;
         return (((size_t)n * a.Hf + ho * a.os + a.oy) * a.Wf + wo * a.os + a.ox) * a.Ctot + a.c_off + c;
     };
     auto res_offset = [&](int m, int c) -> size_t {
-        if (GEN && a.Rs) return (size_t)m * a.Rs + c;
-        if (!(GEN && a.res_up)) return out_offset(m, c);
+        if (a.Rs) return (size_t)m * a.Rs + c;
+        if (!(GEN == 1 && a.res_up)) return out_offset(m, c);
         const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
         const int ho = r / a.Wo, wo = r - ho * a.Wo;
         const int Hr = (a.Ho + 1) >> 1, Wr = (a.Wo + 1) >> 1;
@@ -1183,8 +1188,10 @@ static int launch_conv_pingpong(ConvArgs &a, hipStream_t s) {
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
     const int lds = 256 * (256 * 2 + 16) + 256 * 4;  // 136,192 B: the epilogue image (>= the 128 KiB of staging buffers) + bias
     constexpr bool HAS_PLAIN = (ABL == 0 || ABL == 4) && MF == 0;
-    const bool plain = HAS_PLAIN && !a.adv && !a.res_up && a.relu != 2 && !a.Rs;
-    auto k = plain ? conv_pingpong_kernel<ABL, MF, !HAS_PLAIN> : conv_pingpong_kernel<ABL, MF, true>;
+    const bool cat_only = a.adv && a.os == 1 && !a.oy && !a.ox && a.Ho == a.Hf && a.Wo == a.Wf;
+    const bool plain = HAS_PLAIN && (!a.adv || cat_only) && !a.res_up;
+    auto k = conv_pingpong_kernel<ABL, MF, 1>;
+    if (plain) k = a.relu == 2 ? conv_pingpong_kernel<ABL, MF, HAS_PLAIN ? 2 : 1> : conv_pingpong_kernel<ABL, MF, HAS_PLAIN ? 0 : 1>;
     if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
