@@ -156,6 +156,7 @@ typedef struct md_conv2d_attrs {
                                     the packed weights are for Cin = x_cin) */
     int32_t res_slice, res_c_off;/* res_slice != 0: residual is [N,Ho,Wo,R] and channels [res_c_off, res_c_off + Cout) are added
                                     (res_c_off % 8 == 0; unit output stride, no res_upsample) */
+    int32_t chain_relu;          /* md_conv2d_chain only: ReLU on the chained (second) conv */
 } md_conv2d_attrs;
 /* Replaces Conv2d -> BatchNorm2d(eval) -> [+ residual] -> ReLU of the reference graphs
  * (centernet/src/resnet.py:109-178,181-252; centerpoint/det3d_ms/models/necks/rpn.py:9-154).
@@ -178,6 +179,17 @@ int md_conv2d_cout_tile(int cout);
  * out: y2[N,Ho,Wo,16] bf16 ; optional trailing workspace (N*Ho*Wo*512 bytes, used only by the two-launch path)
  * extra: md_conv2d_attrs of the FIRST conv (relu must be 1, plain addressing). */
 int md_conv2d_head(MD_AOT_ARGS);
+
+/* The bottleneck's expand conv chained into the next block's reduce conv (centernet/src/resnet.py:139-178, two consecutive
+ * Bottleneck cells: conv3 + bn3 + residual + relu of block i, conv1 + bn1 + relu of block i+1): y = act(conv1x1(x) + residual)
+ * with 256 output channels AND y2 = act2(conv1x1(y)) with 64 or 128 channels in ONE launch -- y2 is computed from the output
+ * tile while it is still in LDS, so the 256-channel tensor is not re-read from HBM.  Same results as two md_conv2d calls
+ * (which is also the fallback for any other shape).
+ * in : x[N,H,W,Cin] bf16, w[256,Kpad] bf16, bias[256] f32, residual[N,H,W,256] bf16 | NULL
+ * out: y[N,H,W,256] bf16
+ * in : w2[C2pad,256] bf16, bias2[C2pad] f32      out: y2[N,H,W,C2] bf16
+ * extra: md_conv2d_attrs of the first conv (kh = kw = 1, stride 1, pad 0) + chain_relu. */
+int md_conv2d_chain(MD_AOT_ARGS);
 
 /* Which kernel the dispatcher launched for the calling host thread's most recent md_conv2d (0 before any call, or when
  * the call returned without launching).  Diagnostic only: lets bench.py attribute per-launch HIP-event timings. */

@@ -68,6 +68,8 @@ struct ConvArgs {
     int stamp;              // diagnostic (variant 25): a mid-grid workgroup overwrites the first output bytes with s_memtime stamps
     int res_up;             // 1: residual is [N, ceil(Ho/2), ceil(Wo/2), Cout], read with nearest 2x upsampling
                             //    (the FPN top-down add fused into the lateral 1x1 conv); plain addressing only
+    int c2;                 // chained 1x1 conv (conv_igemm_kernel<.., CHAIN>): its output channels (64 or 128); w2 [>= c2][256], b2, y2
+    int relu2;              // ReLU on the chained conv's output
     int Xs;                 // pixel stride of x in channels (== Cin unless the input is a channel slice of a wider tensor;
                             // a.x then already points at the slice's first channel)
     int Rs;                 // 0: the residual has the output's layout; > 0: residual pixel m, channel c at m*Rs + c (a channel
@@ -137,8 +139,11 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 
 // instantiations for ReLU-or-none / SiLU layers whose output is a whole tensor or a channel range of a concat buffer
 // (offset = m * Ctot + c_off + c): the division-heavy address code of the general epilogue is compiled out (it was 2/3 of the
 // kernel's instructions) and the activation is a compile-time choice.
-template <int NT, int WC, int WP, int FC, int FP, int MODE, int MF = 0, int GEN = 1>
-__global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
+// CHAIN 1 / 2 (CT = 256 = all output channels of the layer, PT = 64): the NEXT layer's 1x1 conv (256 -> 64 / 128 channels, + bias
+// [+ ReLU]) is computed from the finished output tile while it is still in LDS -- the bottleneck's expand conv (+ residual + ReLU)
+// chained into the following block's reduce conv, whose 256-channel input is then never re-read from HBM.
+template <int NT, int WC, int WP, int FC, int FP, int MODE, int MF = 0, int GEN = 1, int CHAIN = 0>
+__global__ __launch_bounds__(NT, NT == 256 ? (CHAIN ? 4 : 3) : 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr bool GLDS = MODE != 0;
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
     constexpr int RPP = NT / 8;                            // tile rows staged per pass of the workgroup
@@ -513,6 +518,70 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
             }
         }
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + off));
+        if constexpr (CHAIN != 0) *reinterpret_cast<u32x4 *>(E + p_local * EP_STRIDE + cc * 16) = v;  // the FINAL value (residual, ReLU)
+    }
+    if constexpr (CHAIN != 0) {
+        static_assert(CHAIN == 0 || (CT == 256 && PT == 64 && WC == 2 && WP == 2 && MF == 0), "chain tile");
+        constexpr int C2 = CHAIN * 64, E2S = C2 * 2 + 16;
+        // second GEMM  y2[px, c2] = sum_k E[px, k] * w2[c2, k]:  A fragments (w2 rows, K contiguous: the packed layout of a 1x1
+        // conv on 256 channels) straight from global / L2 -- requested before the barrier so their latency overlaps it --,
+        // B fragments (pixels) from the epilogue image.  Wave (wc, wp): c2 fragments wc*CHAIN + f, pixel fragment wp.
+        f32x16 acc2[CHAIN];
+        float4 bv2[CHAIN][4];
+#pragma unroll
+        for (int f = 0; f < CHAIN; ++f) {
+            if (CHAIN > 1) break;  // two fragments per wave: requested after the MFMAs instead (register budget of four waves / SIMD)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv2[f][g] = *reinterpret_cast<const float4 *>(a.b2 + (wc * CHAIN + f) * 32 + 8 * g + 4 * lh);
+        }
+#pragma unroll
+        for (int f = 0; f < CHAIN; ++f) {
+            const uint16_t *wrow = a.w2 + (size_t)((wc * CHAIN + f) * 32 + lr) * CT + lh * 8;
+            bf16x8 fa2[CT / 16];
+#pragma unroll
+            for (int kk = 0; kk < CT / 16; ++kk) fa2[kk] = *reinterpret_cast<const bf16x8 *>(wrow + kk * 16);
+            if (f == 0) __syncthreads();  // every final value of the tile is in the image
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[f][e] = 0.f;
+            const char *Bp = E + (wp * 32 + lr) * EP_STRIDE + lh * 16;
+#pragma unroll
+            for (int kk = 0; kk < CT / 16; ++kk) {
+                const bf16x8 fb2 = *reinterpret_cast<const bf16x8 *>(Bp + kk * 32);
+                acc2[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2[kk], fb2, acc2[f], 0, 0, 0);
+            }
+        }
+        if constexpr (CHAIN > 1) {
+#pragma unroll
+            for (int f = 0; f < CHAIN; ++f)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bv2[f][g] = *reinterpret_cast<const float4 *>(a.b2 + (wc * CHAIN + f) * 32 + 8 * g + 4 * lh);
+        }
+        __syncthreads();  // all waves are done reading the image: reuse it for the [pixel][c2] transpose
+#pragma unroll
+        for (int f = 0; f < CHAIN; ++f) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c_local = (wc * CHAIN + f) * 32 + 8 * g + 4 * lh;
+                const f32x2 s01 = (f32x2){acc2[f][4 * g + 0], acc2[f][4 * g + 1]} + (f32x2){bv2[f][g].x, bv2[f][g].y};
+                const f32x2 s23 = (f32x2){acc2[f][4 * g + 2], acc2[f][4 * g + 3]} + (f32x2){bv2[f][g].z, bv2[f][g].w};
+                uint2 pk;
+                pk.x = pk_bf16(s01.x, s01.y);
+                pk.y = pk_bf16(s23.x, s23.y);
+                if (a.relu2) { pk.x = pk_relu_bf16(pk.x); pk.y = pk_relu_bf16(pk.y); }
+                *reinterpret_cast<uint2 *>(E + (wp * 32 + lr) * E2S + c_local * 2) = pk;
+            }
+        }
+        __syncthreads();
+        constexpr int CPP2 = C2 / 8;
+#pragma unroll
+        for (int it = 0; it < PT * CPP2 / NT; ++it) {
+            const int e = tid + it * NT;
+            const int p_local = e / CPP2, cc = e % CPP2;
+            const int m = pix0 + p_local;
+            if (m >= a.M) continue;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(E + p_local * E2S + cc * 16);
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y2 + (size_t)m * C2 + cc * 8));
+        }
     }
     if (a.stamp && blockIdx.x == gridDim.x / 2) {
         stp[5] = __builtin_readcyclecounter();
@@ -557,6 +626,24 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
+
+// 1x1 conv (256 output channels, plain addressing) + the chained 1x1 conv of the next layer (a.c2 = 64 / 128 channels)
+static int launch_conv_chain(ConvArgs &a, hipStream_t s) {
+    constexpr int CT = 256, PT = 64;
+    g_last_kernel = MD_CONV_KERNEL_OTHER;
+    a.n_ctiles = 1;
+    a.n_ptiles = (a.M + PT - 1) / PT;
+    a.single_buf = 1;
+    constexpr int tile_bytes = (CT + PT) * ROWB, ep_bytes = PT * (CT * 2 + 16);
+    a.bias_lds_off = ep_bytes;            // the bias copy sits behind the epilogue image, inside the (dead) staging buffer:
+    const int lds = tile_bytes > ep_bytes + CT * 4 ? tile_bytes : ep_bytes + CT * 4;   // 40 KiB -> four workgroups per CU
+    a.pt_per_xcd = (a.n_ptiles + 7) / 8;
+    const long long blocks = (long long)a.pt_per_xcd * 8;
+    if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
+    auto k = a.c2 == 64 ? conv_igemm_kernel<256, 2, 2, 4, 1, 2, 0, 0, 1> : conv_igemm_kernel<256, 2, 2, 4, 1, 2, 0, 0, 2>;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with HALO REUSE.
@@ -1216,6 +1303,9 @@ struct HeadArgs {
     const uint16_t *w2;
     const float *b2;
     uint16_t *y2;
+    int chain = 0;   // 0: the fused RPN head (y2 has 16 channels, y is not written); 1: a chained 1x1 conv (y AND y2 written)
+    int c2 = 16;     // channels of y2
+    int relu2 = 0;
 };
 #define MD_ERR_UNSUPPORTED_INTERNAL 100  // conv2d_entry with a head on a layer the fused kernel does not take
 
@@ -1250,7 +1340,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
                 void *p2[5] = {(char *)params[0] + n0 * x_img, params[1], params[2],
                                params[3] ? (void *)((char *)params[3] + n0 * r_img) : nullptr, (char *)params[4] + n0 * y_img};
                 HeadArgs h2;
-                if (head) { h2 = *head; h2.y2 += n0 * shapes[4][1] * shapes[4][2] * 16; }
+                if (head) { h2 = *head; h2.y2 += n0 * shapes[4][1] * shapes[4][2] * head->c2; }
                 const int rc = conv2d_entry(nparam, p2, ndims, sh2, dtypes, stream, extra, head ? &h2 : nullptr);
                 if (rc != MD_OK) return rc;
             }
@@ -1352,6 +1442,13 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     const double sb_last = (double)(sb_blocks % 1024) / 1024.0;
     const double t_sb = (double)(sb_blocks / 1024) * 4.0 + (sb_blocks % 1024 ? 1.5 + 2.5 * sb_last : 0.0);
     const bool pp_ok = fast && dma_ok && a.Cout % 256 == 0 && a.Kpad >= 1024 && pp_blocks >= 128 && t_pp <= t_sb;
+    if (head && head->chain) {
+        if (!(fast && dma_ok && a.Cout == 256 && cout_pad == 256 && !a.adv && !a.res_up && !a.Rs && a.relu != 2 && a.pointwise &&
+              a.Kpad == a.Kreal && (head->c2 == 64 || head->c2 == 128) && variant == 0))
+            return MD_ERR_UNSUPPORTED_INTERNAL;
+        a.w2 = head->w2; a.b2 = head->b2; a.y2 = head->y2; a.c2 = head->c2; a.relu2 = head->relu2;
+        return launch_conv_chain(a, s);
+    }
     if (head) {
         if (!(fast && dma_ok && a.Cout == 256 && !a.adv && !a.res && a.relu == 1 && pp_blocks >= 64)) return MD_ERR_UNSUPPORTED_INTERNAL;
         a.w2 = head->w2; a.b2 = head->b2; a.y2 = head->y2;
@@ -1425,5 +1522,37 @@ extern "C" int md_conv2d_head(MD_AOT_ARGS) {
     int64_t *sh1[5] = {sy, sw2, sb2, snull, shapes[5]};
     const char *dt1[5] = {"bfloat16", "bfloat16", "float32", nullptr, "bfloat16"};
     void *p1[5] = {tmp.ptr, params[3], params[4], nullptr, params[5]};
+    return conv2d_entry(5, p1, nd1, sh1, dt1, stream, &a1, nullptr);
+}
+
+// 1x1 conv to 256 channels (+ residual, + ReLU: the bottleneck's expand conv) followed by the NEXT layer's 1x1 conv on those 256
+// channels (64 or 128 outputs, + bias, optional ReLU), both results written: one launch where the chained kernel applies
+// (conv_igemm_kernel<.., CHAIN>: the second conv is computed from the output tile in LDS), otherwise two md_conv2d launches.
+extern "C" int md_conv2d_chain(MD_AOT_ARGS) {
+    // in: x[N,H,W,Cin], w[256,Kpad], bias[256], residual[N,H,W,256] | NULL ; out: y[N,H,W,256] ; in: w2[C2pad,256], bias2[C2pad] ;
+    // out: y2[N,H,W,C2]
+    if (nparam != 8) return MD_ERR_NPARAM;
+    if (!params || !extra || !ndims || !shapes || !params[1] || !params[2] || !params[5] || !params[6]) return MD_ERR_ARG;
+    if (!dtype_is(dtypes, 5, "bfloat16") || !dtype_is(dtypes, 6, "float32") || !dtype_is(dtypes, 7, "bfloat16")) return MD_ERR_ARG;
+    if (ndims[0] != 4 || ndims[4] != 4 || ndims[5] != 2 || ndims[7] != 4) return MD_ERR_ARG;
+    const md_conv2d_attrs *at = (const md_conv2d_attrs *)extra;
+    const int64_t C2 = shapes[7][3];
+    if (shapes[4][3] != 256 || shapes[5][1] != 256 || C2 < 8 || C2 % 8 || shapes[5][0] < C2 || numel(ndims, shapes, 6) < C2 ||
+        shapes[7][0] != shapes[4][0] || shapes[7][1] != shapes[4][1] || shapes[7][2] != shapes[4][2] || at->adv || at->res_upsample)
+        return MD_ERR_ARG;
+    if (numel(ndims, shapes, 7) == 0) return MD_OK;
+    if (!params[7]) return MD_ERR_ARG;
+    HeadArgs head = {(const uint16_t *)params[5], (const float *)params[6], (uint16_t *)params[7], 1, (int)C2, at->chain_relu != 0};
+    int rc = conv2d_entry(5, params, ndims, shapes, dtypes, stream, extra, &head);
+    if (rc != MD_ERR_UNSUPPORTED_INTERNAL) return rc;
+    rc = conv2d_entry(5, params, ndims, shapes, dtypes, stream, extra, nullptr);
+    if (rc != MD_OK) return rc;
+    md_conv2d_attrs a1 = {};
+    a1.kh = a1.kw = 1; a1.stride = 1; a1.pad = 0; a1.relu = at->chain_relu != 0; a1.variant = 0;
+    int64_t snull[1] = {0};
+    int nd1[5] = {4, 2, ndims[6], 0, 4};
+    int64_t *sh1[5] = {shapes[4], shapes[5], shapes[6], snull, shapes[7]};
+    const char *dt1[5] = {"bfloat16", "bfloat16", "float32", nullptr, "bfloat16"};
+    void *p1[5] = {params[4], params[5], params[6], nullptr, params[7]};
     return conv2d_entry(5, p1, nd1, sh1, dt1, stream, &a1, nullptr);
 }

@@ -192,3 +192,32 @@ def test_end_to_end_agreement_in_map_units():
     assert r["bf16-matched oracle"]["n_oracle"] > 20
     assert r["bf16-matched oracle"]["AP"] >= 0.93 and r["bf16-matched oracle"]["AR100"] >= 0.95, r
     assert r["fp32 oracle"]["AP"] >= 0.70, r
+
+
+def test_chained_bottlenecks_match_unchained_and_oracle():
+    """A 64-wide Bottleneck ResNet (stage 2 has 256 channels): with the expand conv chained into the next block's reduce conv
+    (md_conv2d_chain, graphs.CHAIN_BLOCKS) the features equal the block-by-block path and the torch-CPU oracle."""
+    from minddet_amd import graphs
+
+    bb = graphs.ResNet(depth=50, base_width=64, layers=[3, 2, 1, 1], seed=9).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    x8 = torch.zeros((2, 96, 160, 8))
+    x8[..., :3] = torch.randn((2, 96, 160, 3), generator=g)
+    xb = x8.to(torch.bfloat16)
+    old = graphs.CHAIN_BLOCKS
+    try:
+        graphs.CHAIN_BLOCKS = True
+        chained = bb(xb.to(DEV))
+        graphs.CHAIN_BLOCKS = False
+        plain = bb(xb.to(DEV))
+    finally:
+        graphs.CHAIN_BLOCKS = old
+    ref = nets.resnet_forward(bb, xb[..., :3].float().permute(0, 3, 1, 2).contiguous(), quant=True)
+    for f_c, f_p, f_ref in zip(chained, plain, ref):
+        rms = f_ref.pow(2).mean().sqrt().item()
+        tol = 3e-2 * max(rms, 1e-3) + 3e-3 * f_ref.abs().max().item()
+        assert (f_c.float() - f_p.float()).abs().max().item() <= tol
+        # ~25 bf16-rounded layers deep: the distance to the oracle is judged as an rms (2 %) with a loose cap on single values
+        d = f_c.float().cpu().permute(0, 3, 1, 2) - f_ref
+        assert d.pow(2).mean().sqrt().item() <= 2e-2 * max(rms, 1e-3)
+        assert d.abs().max().item() <= 0.1 * f_ref.abs().max().item()
