@@ -608,7 +608,9 @@ __global__ __launch_bounds__(256) void roi_align_c32_kernel(RoiArgs a, const flo
         f32x2 acc[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = (f32x2){0.f, 0.f};
-        const uint16_t *base = L.feat + (size_t)b * L.H * L.W * a.C + c32 * 32;
+        // the thread's four 16-B chunks are cv chunks apart (chunks c32, c32 + cv, ...): a load instruction of the cv threads of a
+        // bin then covers one contiguous cv*16-B run of the pixel (whole 128-B lines for C = 256) instead of every fourth chunk
+        const uint16_t *base = L.feat + (size_t)b * L.H * L.W * a.C + c32 * 8;
         for (int iy = 0; iy < g; ++iy) {
             const float y = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)g;
             for (int ix = 0; ix < g; ++ix) {
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(256) void roi_align_c32_kernel(RoiArgs a, const flo
                 for (int tp = 0; tp < 4; ++tp) {
                     uint4 v[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const uint4 *>(ptr[tp])[q];
+                    for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const uint4 *>(ptr[tp])[q * cv];
                     const f32x2 w2 = (f32x2){wt[tp], wt[tp]};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(256) void roi_align_c32_kernel(RoiArgs a, const flo
             }
         }
         const float inv = 1.f / (float)(g * g);
-        uint4 *dst = reinterpret_cast<uint4 *>(out + e * 32);
+        uint4 *dst = reinterpret_cast<uint4 *>(out + (e / cv) * a.C + c32 * 8);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint4 o;
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(256) void roi_align_c32_kernel(RoiArgs a, const flo
             o.y = rpk_bf16(acc[q * 4 + 1].x * inv, acc[q * 4 + 1].y * inv);
             o.z = rpk_bf16(acc[q * 4 + 2].x * inv, acc[q * 4 + 2].y * inv);
             o.w = rpk_bf16(acc[q * 4 + 3].x * inv, acc[q * 4 + 3].y * inv);
-            dst[q] = o;
+            dst[q * cv] = o;
         }
     }
 }
