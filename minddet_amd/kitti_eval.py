@@ -17,9 +17,12 @@ recall points 0, 4, ..., 40 (11-point) or 1..40 (R40).  AOS accumulates (1 + cos
 
 The rotated BEV intersections come from `det_ops.rotate_iou_gpu_eval` (md_rotate_iou_eval, the HIP counterpart of
 eval_gpu/rotate_iou.py:264-340) exactly where the reference calls its CUDA kernel; everything else is host numpy like the
-reference's.  The reference's evaluators need numba (absent here) and ship no fixture: this module is checked against a
-scalar restatement of the matching rules and hand-computed answers (tests/test_kitti_eval_cpu.py) -- parity with the
-reference run on real KITTI results is unpinned.
+reference's.  Pinning (tests/test_kitti_eval_cpu.py): the "ms" protocol reproduces the reference's own outputs -- result text,
+mAP table, 41-point precision rows, clean_data flags, get_thresholds -- on 223 synthetic images (tests/golden/
+kitti_eval_vectors.json, written by tests/golden/gen_kitti_eval.py from pointpillars/src/core/eval_utils.py imported with numba's
+decorators as identities).  The "full" protocol shares that machinery; its BEV / 3D / AOS parts (eval_gpu/eval.py needs
+numba.cuda) are checked against a scalar restatement of the matching rules and hand-computed answers only: parity unpinned there,
+as is any run on real KITTI results.  Reference quirk: eval_utils.get_split_parts has no guard, fewer than 50 images crash it.
 """
 import numpy as np
 
