@@ -22,7 +22,8 @@ mAP table, 41-point precision rows, clean_data flags, get_thresholds -- on 223 s
 kitti_eval_vectors.json, written by tests/golden/gen_kitti_eval.py from pointpillars/src/core/eval_utils.py imported with numba's
 decorators as identities).  The "full" protocol shares that machinery; its BEV / 3D / AOS parts (eval_gpu/eval.py needs
 numba.cuda) are checked against a scalar restatement of the matching rules and hand-computed answers only: parity unpinned there,
-as is any run on real KITTI results.  Reference quirk: eval_utils.get_split_parts has no guard, fewer than 50 images crash it.
+as is any run on real KITTI results.  The lidar -> camera -> image box geometry reproduces the reference's box_ops.py outputs (same
+golden file); the annotation writer's filter rules (predict.py needs skimage through kitti_common: not importable) are restated.  Reference quirk: eval_utils.get_split_parts has no guard, fewer than 50 images crash it.
 """
 import numpy as np
 

@@ -79,6 +79,23 @@ def main():
     for n, ngt in ((5, 5), (30, 40), (120, 100), (3, 50)):
         s = np.round(rng.uniform(0, 1, n), 3)
         out["thresholds"].append(dict(scores=s.tolist(), num_gt=ngt, thresholds=[float(v) for v in ref.get_thresholds(s.copy(), ngt)]))
+    # result-format geometry (pointpillars/src/core/box_ops.py: box_lidar_to_camera :521-546, boxes3d_kitti_camera_to_imageboxes
+    # :653-668) on a KITTI-like calibration
+    from src.core import box_ops
+
+    rect = np.eye(4)
+    rect[:3, :3] = [[0.9999, 0.0098, -0.0074], [-0.0099, 0.9999, -0.0043], [0.0074, 0.0044, 0.9999]]
+    trv2c = np.eye(4)
+    trv2c[:3, :] = [[0.0075, -0.9999, -0.0006, -0.0041], [0.0148, 0.0007, -0.9998, -0.0763], [0.9998, 0.0075, 0.0148, -0.2718]]
+    p2 = np.eye(4)
+    p2[:3, :] = [[721.5377, 0.0, 609.5593, 44.85728], [0.0, 721.5377, 172.854, 0.2163791], [0.0, 0.0, 1.0, 0.002745884]]
+    n = 40
+    boxes = np.stack([rng.uniform(2, 60, n), rng.uniform(-25, 25, n), rng.uniform(-2.2, -0.4, n), rng.uniform(0.5, 2.0, n),
+                      rng.uniform(0.6, 4.5, n), rng.uniform(1.3, 1.9, n), rng.uniform(-3.2, 3.2, n)], 1)
+    cam = box_ops.box_lidar_to_camera(boxes, rect, trv2c)
+    img = box_ops.boxes3d_kitti_camera_to_imageboxes(cam, p2)
+    out["geometry"] = dict(rect=rect.tolist(), trv2c=trv2c.tolist(), p2=p2.tolist(), boxes_lidar=boxes.tolist(), boxes_camera=np.asarray(cam).tolist(),
+                           boxes_image=np.asarray(img).tolist())
     json.dump(out, open(os.path.join(HERE, "kitti_eval_vectors.json"), "w"))
     print("wrote", sum(len(c["gt"]) for c in out["cases"]), "images;", out["cases"][-1]["text"])
 

@@ -235,3 +235,13 @@ def test_ms_protocol_equals_the_reference_outputs():
                     nv, ig, idt, dc = ke.clean_data(g, d, c, diff, ke.CLASS_NAMES_MS)
                     assert [nv, list(ig), list(idt), len(dc)] == case["clean"][i][c]
                 i += 1
+
+
+def test_result_geometry_equals_the_reference_outputs():
+    """box_lidar_to_camera / boxes3d_kitti_camera_to_imageboxes of the reference's box_ops.py on a KITTI-like calibration."""
+    g = _golden()["geometry"]
+    rect, trv2c, p2 = np.array(g["rect"]), np.array(g["trv2c"]), np.array(g["p2"])
+    cam = ke.box_lidar_to_camera(np.array(g["boxes_lidar"]), rect, trv2c)
+    np.testing.assert_allclose(cam, np.array(g["boxes_camera"]), rtol=0, atol=1e-12)
+    img = ke.camera_boxes_to_image_boxes(cam, p2)
+    np.testing.assert_allclose(img, np.array(g["boxes_image"]), rtol=1e-6, atol=1e-4)
