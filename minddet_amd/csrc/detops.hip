@@ -757,27 +757,51 @@ __global__ void centerpoint_decode_kernel(const uint16_t *__restrict__ head, CpA
 // YOLOv5 Detect decode: per (cell, anchor): sigmoid of the 5+nc outputs; xy = (2s - 0.5 + grid) * stride,
 // wh = (2s)^2 * anchor; score = obj * max_c cls_c (single-label mode), label = argmax.
 struct YoloArgs { int H, W, Cp, nc, A; float stride, aw[3], ah[3], thr; int off, total; };
-__global__ void yolo_decode_kernel(const uint16_t *__restrict__ head, YoloArgs a, int B, float *__restrict__ boxes,
-                                   float *__restrict__ scores, int *__restrict__ labels) {
-    const int per = a.H * a.W * a.A;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= B * per) return;
-    const int b = e / per, r = e % per;
-    const int an = r % a.A, loc = r / a.A;
+// Head rows are staged through LDS with coalesced 16-B loads (cells consecutive cells x Cp channels; rows padded by one dword so
+// that the per-(cell, anchor) scalar reads that follow spread over the banks): r01 the direct 2-byte global reads at a 170-B lane
+// stride made this kernel 24 % of the YOLOv5s step.  The class arg-max runs on the logits (sigmoid is monotonic; logits are
+// clamped to the range where the fp32 sigmoid still separates values, so saturated ties resolve to the first index as they
+// would after the sigmoid) and only the winner is passed through the sigmoid.
+__device__ __forceinline__ void stage_head_rows(const uint16_t *__restrict__ head, unsigned *sm, long long cell0, long long cells_total,
+                                                int cells, int Cp) {
+    const int chunks = Cp / 8, rowdw = Cp / 2 + 1;
+    for (int i = threadIdx.x; i < cells * chunks; i += blockDim.x) {
+        const int c = i / chunks, q = i - c * chunks;
+        if (cell0 + c < cells_total) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(head + (size_t)(cell0 + c) * Cp + q * 8);
+            unsigned *d = sm + c * rowdw + q * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ float logit_key(float v) { return fminf(fmaxf(v, -87.f), 16.f); }
+
+__global__ __launch_bounds__(256) void yolo_decode_kernel(const uint16_t *__restrict__ head, YoloArgs a, int B, int cells,
+                                                          float *__restrict__ boxes, float *__restrict__ scores, int *__restrict__ labels) {
+    extern __shared__ unsigned ysm[];
+    const long long cells_total = (long long)B * a.H * a.W, cell0 = (long long)blockIdx.x * cells;
+    stage_head_rows(head, ysm, cell0, cells_total, cells, a.Cp);
+    const int t = threadIdx.x;
+    if (t >= cells * a.A) return;
+    const int c = t / a.A, an = t - c * a.A;
+    const long long cell = cell0 + c;
+    if (cell >= cells_total) return;
+    const int b = (int)(cell / (a.H * a.W)), loc = (int)(cell - (long long)b * a.H * a.W);
     const int gx = loc % a.W, gy = loc / a.W;
-    const uint16_t *h = head + ((size_t)b * a.H * a.W + loc) * a.Cp + an * (5 + a.nc);
+    const uint16_t *h = reinterpret_cast<const uint16_t *>(ysm + c * (a.Cp / 2 + 1)) + an * (5 + a.nc);
     auto sg = [](float v) { return 1.0f / (1.0f + expf(-v)); };
     const float sx = sg(rbf2f(h[0])), sy = sg(rbf2f(h[1])), sw = sg(rbf2f(h[2])), sh = sg(rbf2f(h[3])), obj = sg(rbf2f(h[4]));
     const float cx = (sx * 2.f - 0.5f + (float)gx) * a.stride, cy = (sy * 2.f - 0.5f + (float)gy) * a.stride;
     const float w = (sw * 2.f) * (sw * 2.f) * a.aw[an], hh = (sh * 2.f) * (sh * 2.f) * a.ah[an];
-    float best = -1.f;
+    float best = -FLT_MAX, best_v = 0.f;
     int lab = 0;
-    for (int c = 0; c < a.nc; ++c) {
-        const float v = sg(rbf2f(h[5 + c]));
-        if (v > best) { best = v; lab = c; }
+    for (int k = 0; k < a.nc; ++k) {
+        const float v = rbf2f(h[5 + k]), key = logit_key(v);
+        if (key > best) { best = key; best_v = v; lab = k; }
     }
-    const float conf = obj * best;
-    const size_t o = (size_t)b * a.total + a.off + r;
+    const float conf = obj * sg(best_v);
+    const size_t o = (size_t)b * a.total + a.off + (size_t)loc * a.A + an;
     *reinterpret_cast<float4 *>(boxes + o * 4) = make_float4(cx - w / 2, cy - hh / 2, cx + w / 2, cy + hh / 2);
     scores[o] = (obj > a.thr && conf > a.thr) ? conf : -FLT_MAX;
     labels[o] = lab;
@@ -788,14 +812,18 @@ __global__ void yolo_decode_kernel(const uint16_t *__restrict__ head, YoloArgs a
 // logits.  distance = sum_i i * softmax(bins)_i ; box = (ax - l, ay - t, ax + r, ay + b) * stride with the anchor point
 // (gx + 0.5, gy + 0.5); score = max_c sigmoid(cls_c), label = first arg-max; score <= conf -> -FLT_MAX.
 struct Yolo8Args { int H, W, Cp, nc, R; float stride, thr; int off, total; };
-__global__ void yolov8_decode_kernel(const uint16_t *__restrict__ head, Yolo8Args a, int B, float *__restrict__ boxes,
-                                     float *__restrict__ scores, int *__restrict__ labels) {
+__global__ __launch_bounds__(256) void yolov8_decode_kernel(const uint16_t *__restrict__ head, Yolo8Args a, int B, int cells,
+                                                            float *__restrict__ boxes, float *__restrict__ scores, int *__restrict__ labels) {
+    extern __shared__ unsigned ysm[];
     const int per = a.H * a.W;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= B * per) return;
-    const int b = e / per, loc = e % per;
+    const long long cells_total = (long long)B * per, cell0 = (long long)blockIdx.x * cells;
+    stage_head_rows(head, ysm, cell0, cells_total, cells, a.Cp);   // see yolo_decode_kernel
+    const int t = threadIdx.x;
+    const long long cell = cell0 + t;
+    if (t >= cells || cell >= cells_total) return;
+    const int b = (int)(cell / per), loc = (int)(cell - (long long)b * per);
     const int gx = loc % a.W, gy = loc / a.W;
-    const uint16_t *h = head + ((size_t)b * per + loc) * a.Cp;
+    const uint16_t *h = reinterpret_cast<const uint16_t *>(ysm + t * (a.Cp / 2 + 1));
     float d[4];
 #pragma unroll
     for (int sd = 0; sd < 4; ++sd) {
@@ -1151,8 +1179,17 @@ extern "C" int md_yolo_decode(MD_AOT_ARGS) {
         numel(ndims, shapes, 3) != (int64_t)B * a.total)
         return MD_ERR_ARG;
     if (B * per == 0) return MD_OK;
-    hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)((B * per + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t *)params[0], a, B, (float *)params[1], (float *)params[2], (int *)params[3]);
+    if (a.Cp % 8) return MD_ERR_ARG;
+    // cells per 256-thread workgroup: A threads per cell, rows of Cp/2 + 1 dwords in at most 60 KiB of LDS
+    int cells = 256 / a.A;
+    if (cells > 64) cells = 64;
+    const int rowb = (a.Cp / 2 + 1) * 4;
+    if (cells * rowb > 60 * 1024) cells = 60 * 1024 / rowb;
+    if (cells < 1) return MD_ERR_SIZE;
+    const long long cells_total = (long long)B * a.H * a.W;
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)((cells_total + cells - 1) / cells)), dim3(256), (size_t)cells * rowb,
+                       (hipStream_t)stream, (const uint16_t *)params[0], a, B, cells, (float *)params[1], (float *)params[2],
+                       (int *)params[3]);
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }
@@ -1225,8 +1262,15 @@ extern "C" int md_yolov8_decode(MD_AOT_ARGS) {
         return MD_ERR_ARG;
     if ((int64_t)B * per == 0) return MD_OK;
     if ((int64_t)B * per > 0x7fffffffLL) return MD_ERR_SIZE;
-    hipLaunchKernelGGL(yolov8_decode_kernel, dim3((unsigned)((B * per + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t *)params[0], a, B, (float *)params[1], (float *)params[2], (int *)params[3]);
+    if (a.Cp % 8) return MD_ERR_ARG;
+    int cells = 128;                                  // one thread per cell; rows of Cp/2 + 1 dwords in at most 60 KiB of LDS
+    const int rowb = (a.Cp / 2 + 1) * 4;
+    if (cells * rowb > 60 * 1024) cells = 60 * 1024 / rowb;
+    if (cells < 1) return MD_ERR_SIZE;
+    const long long cells_total = (long long)B * per;
+    hipLaunchKernelGGL(yolov8_decode_kernel, dim3((unsigned)((cells_total + cells - 1) / cells)), dim3(256), (size_t)cells * rowb,
+                       (hipStream_t)stream, (const uint16_t *)params[0], a, B, cells, (float *)params[1], (float *)params[2],
+                       (int *)params[3]);
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }
