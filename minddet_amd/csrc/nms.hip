@@ -327,6 +327,7 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long 
     const int nb = (n + TILE - 1) / TILE;
     int total = 0;  // kept so far (uniform)
     for (int blk = 0; blk < nb; ++blk) {
+        if (max_output > 0 && total >= max_output) break;  // quota reached (uniform): nothing later can be kept
         const int base = blk * TILE;
         if (wave == 0) {
             const int r = base + lane;
