@@ -379,6 +379,15 @@ typedef struct md_clip_attrs {
 int md_sigmoid_clip(MD_AOT_ARGS);
 /* heat * (heat == maxpool3x3_same(heat)): in heat[B,C,H,W] f32 ; out same shape */
 int md_heat_nms(MD_AOT_ARGS);
+typedef struct md_heat_peaks_attrs {
+    int32_t c0, num_classes; /* heat-map channels [c0, c0 + num_classes) of the head (c0 % 8 == 0) */
+    float lo, hi;            /* clip range of md_sigmoid_clip */
+} md_heat_peaks_attrs;
+/* The CenterNet head's heat-map post-processing in one pass, same arithmetic per element as the three ops it replaces
+ * (centernet/src/centernet_det.py:374-399 sigmoid + clip of the `hm` head, centernet/src/decode.py:40-64 `NMS` = 3x3 max-pool peak
+ * test): in head[B,H,W,Cp] bf16 NHWC ; out heat[B,num_classes,H,W] f32 NCHW (sigmoid-clipped value where it is the maximum of its
+ * 3x3 neighbourhood, else 0), hm[B,num_classes,H,W] f32 (sigmoid-clipped values; pointer may be NULL). extra: md_heat_peaks_attrs. */
+int md_heat_peaks(MD_AOT_ARGS);
 /* in top_score[B,K] f32, top_ind2[B,K] i32 (index into C*K), cls_inds[B,C,K] i32, wh[B,2,H,W] f32,
  *    reg[B,2,H,W] f32 or NULL ; out det[B,K,6] f32 (x1,y1,x2,y2,score,cls), inds[B,K] i32, cls[B,K] i32 */
 int md_centernet_assemble(MD_AOT_ARGS);

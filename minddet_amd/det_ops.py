@@ -368,6 +368,20 @@ def sigmoid_clip(x, lo=1e-4, hi=1 - 1e-4):
     return y
 
 
+class _PeakAttrs(ctypes.Structure):
+    _fields_ = [("c0", ctypes.c_int32), ("num_classes", ctypes.c_int32), ("lo", ctypes.c_float), ("hi", ctypes.c_float)]
+
+
+def heat_peaks(head, c0, num_classes, with_hm=False, lo=1e-4, hi=1 - 1e-4):
+    """head [B,H,W,Cp] bf16 NHWC -> (heat [B,nc,H,W] f32 = sigmoid-clipped heat map zeroed off its 3x3 maxima, hm or None):
+    nhwc_to_nchw_f32 + sigmoid_clip + md_heat_nms in one md_heat_peaks launch, bit-identical to the three."""
+    b, h, w, _ = head.shape
+    heat = torch.empty((b, num_classes, h, w), dtype=torch.float32, device=head.device)
+    hm = torch.empty_like(heat) if with_hm else None
+    _lib.call("md_heat_peaks", [head, heat, hm], extra=_PeakAttrs(int(c0), int(num_classes), float(lo), float(hi)))
+    return heat, hm
+
+
 class DetectionDecode:
     """Mirror of centernet/src/decode.py:123-196 (NMS :40-64, GatherTopK :90-109): feature dict with
     'hm' [B,C,H,W] (already sigmoid+clip), 'wh', 'reg' [B,2,H,W] fp32 NCHW -> detections [B,K,6]."""
@@ -376,17 +390,21 @@ class DetectionDecode:
         self.reg_offset, self.K = reg_offset, K
 
     def __call__(self, feature, return_indices=False):
-        hm, wh = _f32c(feature["hm"]), _f32c(feature["wh"])
+        wh = _f32c(feature["wh"])
         reg = _f32c(feature["reg"]) if self.reg_offset else None
-        B, C, H, W = hm.shape
         K = self.K
-        heat = torch.empty_like(hm)
-        _lib.call("md_heat_nms", [hm, heat])
+        if feature.get("heat") is not None:      # peaks already extracted (heat_peaks: the fused head post-processing)
+            heat = _f32c(feature["heat"])
+        else:
+            hm = _f32c(feature["hm"])
+            heat = torch.empty_like(hm)
+            _lib.call("md_heat_nms", [hm, heat])
+        B, C, H, W = heat.shape
         v1, i1 = top_k(heat.view(B * C, H * W), K)           # per-class top-K  (decode.py:96)
         v2, i2 = top_k(v1.view(B, C * K), K)                 # global top-K     (decode.py:101)
-        det = torch.empty((B, K, 6), dtype=torch.float32, device=hm.device)
-        inds = torch.empty((B, K), dtype=torch.int32, device=hm.device)
-        cls = torch.empty((B, K), dtype=torch.int32, device=hm.device)
+        det = torch.empty((B, K, 6), dtype=torch.float32, device=heat.device)
+        inds = torch.empty((B, K), dtype=torch.int32, device=heat.device)
+        cls = torch.empty((B, K), dtype=torch.int32, device=heat.device)
         _lib.call("md_centernet_assemble", [v2, i2, i1.view(B, C, K), wh, reg, det, inds, cls])
         return (det, inds, cls) if return_indices else det
 

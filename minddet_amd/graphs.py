@@ -622,10 +622,11 @@ class CenterNet:
     def forward(self, images, return_aux=False):
         head = self.features(images)
         nc = self.num_classes
-        hm = det_ops.sigmoid_clip(nn_ops.nhwc_to_nchw_f32(head, 0, nc))
+        # heat map: NHWC bf16 -> NCHW fp32, sigmoid + clip and the 3x3 peak test in one launch (md_heat_peaks)
+        heat, hm = det_ops.heat_peaks(head, 0, nc, with_hm=return_aux)
         wh = nn_ops.nhwc_to_nchw_f32(head, nc, 2)
         reg = nn_ops.nhwc_to_nchw_f32(head, nc + 2, 2)
-        det, inds, cls = self.decode({"hm": hm, "wh": wh, "reg": reg}, return_indices=True)
+        det, inds, cls = self.decode({"hm": hm, "heat": heat, "wh": wh, "reg": reg}, return_indices=True)
         if return_aux:
             return det, dict(head=head, hm=hm, wh=wh, reg=reg, inds=inds, cls=cls)
         return det

@@ -319,3 +319,28 @@ def test_centernet_post_process_merge():
     np.testing.assert_allclose(boxes.cpu().numpy(), ref_boxes[alive], atol=1e-3)
     np.testing.assert_allclose(scores.cpu().numpy(), surv_scores[alive], rtol=3e-6, atol=1e-7)
     np.testing.assert_array_equal(cls.cpu().numpy(), dets[alive, 5].astype(np.int32))
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 128, 88, 80), (1, 37, 70, 24, 19), (3, 8, 64, 16, 3), (1, 5, 3, 8, 8)])
+def test_heat_peaks_equals_the_three_passes(shape):
+    """md_heat_peaks == md_nhwc_to_nchw_f32 -> md_sigmoid_clip -> md_heat_nms, bit for bit (ragged tiles, class counts that are
+    not a multiple of the kernel's 16-class groups, plateaus from the clip)."""
+    from minddet_amd import _lib, det_ops, nn_ops
+
+    B, H, W, Cp, nc = shape
+    g = torch.Generator().manual_seed(H * W)
+    head = (torch.randn((B, H, W, Cp), generator=g) * 6).to(torch.bfloat16)      # |x| up to ~20: both clip ends are hit
+    head[:, : H // 2, : W // 2, 0] = 3.0                                            # a plateau: every pixel equals its 3x3 max
+    hd = head.to(DEV)
+    hm_ref = det_ops.sigmoid_clip(nn_ops.nhwc_to_nchw_f32(hd, 0, nc))
+    heat_ref = torch.empty_like(hm_ref)
+    _lib.call("md_heat_nms", [hm_ref, heat_ref])
+    heat, hm = det_ops.heat_peaks(hd, 0, nc, with_hm=True)
+    assert torch.equal(hm, hm_ref) and torch.equal(heat, heat_ref)
+    heat2, none = det_ops.heat_peaks(hd, 0, nc)
+    assert none is None and torch.equal(heat2, heat_ref)
+    assert (heat_ref > 0).sum() > 0 and (heat_ref == 0).sum() > 0
+    with pytest.raises(_lib.MindDetHipError):
+        det_ops.heat_peaks(hd, 4, nc)
+    with pytest.raises(_lib.MindDetHipError):
+        det_ops.heat_peaks(hd, 0, Cp + 8)
