@@ -1454,6 +1454,18 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
         a.w2 = head->w2; a.b2 = head->b2; a.y2 = head->y2;
         return launch_conv_pingpong_head(a, s);
     }
+    // 3x3 layers on <= 256 channels: the 64-cout halo-reuse kernel at four workgroups per CU beats the 128x128 kernel wherever
+    // the ping-pong kernel does not apply, and beats the ping-pong kernel when its 256x256 tiles fill the last of several rounds
+    // badly (r01 tools/conv_ab_yolo.py, batch 32: 128->128 @80x80 +11 %, 256->256 @20x20 +16 %, 256->256 @80x80 (3.1 rounds) +8 %;
+    // one-round grids and K = 4608 layers stay where they were)
+    const long long pp_rounds = (pp_blocks + 255) / 256;
+    const bool pp_ragged = pp_rounds >= 2 && (double)pp_blocks < 0.85 * (double)(pp_rounds * 256);
+    const bool cat_only_h = !a.adv || (a.os == 1 && a.oy == 0 && a.ox == 0 && a.Ho == a.Hf && a.Wo == a.Wf && a.pad_top == a.pad &&
+                                       a.pad_left == a.pad && (!a.res || a.Rs));
+    const bool halo64_first = variant == 0 && !head && dma_ok && cat_only_h && a.korder == 1 && a.kh == 3 && a.kw == 3 && a.stride == 1 &&
+                              a.pad == 1 && a.Cin % 64 == 0 && a.Cin <= 256 && a.Cout % 64 == 0 && cout_pad % 64 == 0 && !a.res_up &&
+                              a.Ho == a.H && a.Wo == a.W && (!pp_ok || pp_ragged);
+    if (halo64_first) return launch_conv3x3_halo<64, true>(a, s);
     if (variant == 0 && pp_ok) return launch_conv_pingpong<0>(a, s);
     if (halo_ok && !a.res_up && variant == 11) return launch_conv3x3_halo<128, false>(a, s);  // superseded by the paths around it
     // 64-cout tiles of the halo kernel at four workgroups per CU (variant 27; auto for Cout <= 64)
@@ -1473,6 +1485,9 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
         if (fast) return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 2>(a, s) : launch_conv<256, 1, 4, 1, 2, 2>(a, s);
         return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 1>(a, s) : launch_conv<256, 1, 4, 1, 2, 1>(a, s);
     }
+    // a grid of fewer than two workgroups per CU with a long K loop: nobody else hides the DMA latency, stage the next tile
+    // while this one is multiplied (512->512 @20x20, batch 32: +11 %)
+    if (variant == 0 && sb_blocks <= 512 && a.Kpad / BK >= 16) a.single_buf = 0;
     if (variant == 1) return launch_conv<256, 2, 2, 2, 2, 0>(a, s);               // register-staged, 64-bit addressing
     if (variant == 5 && fast) return launch_conv<256, 2, 2, 2, 2, 2, 1>(a, s);    // 128x128, 16x16x32 MFMA
     return fast ? launch_conv<256, 2, 2, 2, 2, 2>(a, s) : launch_conv<256, 2, 2, 2, 2, 1>(a, s);
