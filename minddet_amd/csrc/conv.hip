@@ -1440,7 +1440,10 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     const long long pp_blocks = (M + 255) / 256 * (a.Cout / 256), sb_blocks = (M + 127) / 128 * ((a.Cout + 127) / 128);
     const double t_pp = (double)((pp_blocks + 255) / 256) * (4.0 / 1.2);
     const double sb_last = (double)(sb_blocks % 1024) / 1024.0;
-    const double t_sb = (double)(sb_blocks / 1024) * 4.0 + (sb_blocks % 1024 ? 1.5 + 2.5 * sb_last : 0.0);
+    // a partial last round costs at least what a workgroup alone on its CU needs for the K loop (~1.3 us per K tile: nobody hides
+    // its DMA latency; measured r01 256->256 3x3 @50x84, batch 32: 2.05 rounds of the 128x128 kernel = 194 us, ping-pong 176 us)
+    const double sb_part = 1.5 + 2.5 * sb_last, sb_lone = 0.0726 * (double)(a.Kpad / BK);
+    const double t_sb = (double)(sb_blocks / 1024) * 4.0 + (sb_blocks % 1024 ? (sb_part > sb_lone ? sb_part : sb_lone) : 0.0);
     const bool pp_ok = fast && dma_ok && a.Cout % 256 == 0 && a.Kpad >= 1024 && pp_blocks >= 128 && t_pp <= t_sb;
     if (head && head->chain) {
         if (!(fast && dma_ok && a.Cout == 256 && cout_pad == 256 && !a.adv && !a.res_up && !a.Rs && a.relu != 2 && a.pointwise &&
@@ -1460,11 +1463,15 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     // one-round grids and K = 4608 layers stay where they were)
     const long long pp_rounds = (pp_blocks + 255) / 256;
     const bool pp_ragged = pp_rounds >= 2 && (double)pp_blocks < 0.85 * (double)(pp_rounds * 256);
+    // ... provided its 8x16-pixel tiles cover the image without much waste (100x168: 8 % idle lanes and the 128x128 kernel is 3 %
+    // ahead), or the whole grid is resident at once anyway (<= 1024 workgroups: latency-bound, the halo kernel's shorter chain wins)
+    const long long h_tiles = (long long)a.N * ((a.H + HT_H - 1) / HT_H) * ((a.W + HT_W - 1) / HT_W);
+    const bool halo_fits = (double)a.H * a.W * a.N >= 0.95 * (double)(h_tiles * HT_H * HT_W) || h_tiles * (a.Cout / 64) <= 1024;
     const bool cat_only_h = !a.adv || (a.os == 1 && a.oy == 0 && a.ox == 0 && a.Ho == a.Hf && a.Wo == a.Wf && a.pad_top == a.pad &&
                                        a.pad_left == a.pad && (!a.res || a.Rs));
     const bool halo64_first = variant == 0 && !head && dma_ok && cat_only_h && a.korder == 1 && a.kh == 3 && a.kw == 3 && a.stride == 1 &&
                               a.pad == 1 && a.Cin % 64 == 0 && a.Cin <= 256 && a.Cout % 64 == 0 && cout_pad % 64 == 0 && !a.res_up &&
-                              a.Ho == a.H && a.Wo == a.W && (!pp_ok || pp_ragged);
+                              a.Ho == a.H && a.Wo == a.W && (!pp_ok || pp_ragged) && halo_fits;
     if (halo64_first) return launch_conv3x3_halo<64, true>(a, s);
     if (variant == 0 && pp_ok) return launch_conv_pingpong<0>(a, s);
     if (halo_ok && !a.res_up && variant == 11) return launch_conv3x3_halo<128, false>(a, s);  // superseded by the paths around it
