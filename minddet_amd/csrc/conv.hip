@@ -1435,14 +1435,15 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     // MFMA-bound layers (K >= 1024, Cout a multiple of 256): the 256x256 ping-pong kernel (measured r01, tools/conv_ab.py:
     // +17 % over the halo kernel on 3x3 256->256, +75 % on the 12544->1024 FC; loses on the HBM-bound K < 1024 layers)
     // and it needs enough 256x256 tiles to fill whole rounds of the 256 CUs (one workgroup per CU, ~1.2x the per-CU rate
-    // of four resident 128x128 workgroups; a partial last round costs a full tile time, while the 128x128 kernel's
-    // stragglers run alone on their CUs and finish faster).  Unit: one 128x128 tile at the full-CU 128x128 rate.
+    // of four resident 128x128 workgroups; a partial last round costs a full tile time there, a large fraction of a round
+    // on the 128x128 kernel -- see below).  Unit: one 128x128 tile at the full-CU 128x128 rate.
     const long long pp_blocks = (M + 255) / 256 * (a.Cout / 256), sb_blocks = (M + 127) / 128 * ((a.Cout + 127) / 128);
     const double t_pp = (double)((pp_blocks + 255) / 256) * (4.0 / 1.2);
     const double sb_last = (double)(sb_blocks % 1024) / 1024.0;
-    // a partial last round costs at least what a workgroup alone on its CU needs for the K loop (~1.3 us per K tile: nobody hides
-    // its DMA latency; measured r01 256->256 3x3 @50x84, batch 32: 2.05 rounds of the 128x128 kernel = 194 us, ping-pong 176 us)
-    const double sb_part = 1.5 + 2.5 * sb_last, sb_lone = 0.0726 * (double)(a.Kpad / BK);
+    // a partial last round is expensive on the single-buffer kernel: the few workgroups left run alone on their CUs, nobody hides
+    // their DMA latency (~1.3 us per K tile).  Measured r01, batch 32: 256->256 3x3 @50x84 = 2.05 rounds: 194 us vs ping-pong
+    // (3 rounds) 176 us; 1024->256 1x1 @50x84: 107 vs 98 us -> a partial round costs 0.6-1.0 of a full one.
+    const double sb_part = 2.5 + 1.5 * sb_last, sb_lone = 0.0726 * (double)(a.Kpad / BK);
     const double t_sb = (double)(sb_blocks / 1024) * 4.0 + (sb_blocks % 1024 ? (sb_part > sb_lone ? sb_part : sb_lone) : 0.0);
     const bool pp_ok = fast && dma_ok && a.Cout % 256 == 0 && a.Kpad >= 1024 && pp_blocks >= 128 && t_pp <= t_sb;
     if (head && head->chain) {
