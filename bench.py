@@ -40,6 +40,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=60,
                     help="images per GPU per step (r01, no instrumentation: 32 -> 1640, 48 -> 1797, 60 -> 1870, 128 -> 1893 images/s; 60 is the largest batch whose P2 tensors stay under the 2 GiB reach of one launch)")
+    ap.add_argument("--bracket", choices=["dominant", "all"], default="dominant",
+                    help="which conv launches of the TIMED region are bracketed by HIP events: only the dominant kernel's (default: "
+                         "the whole-set table then comes from the last warmup step, where every launch is bracketed; 2 events per "
+                         "launch cost ~1.5 %% of the step when all 68 launches carry them) or all of them")
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "faster_rcnn", "faster_rcnn_r50_fpn.py"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -88,7 +92,16 @@ def main():
     KNAMES = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<128x128>", 3: "conv_igemm_kernel<small cout>",
               4: "conv_igemm_kernel<generic K>", 5: "conv3x3_halo_kernel", 6: "conv variant"}
 
+    sel = {"calls": None, "idx": 0}    # calls: None = bracket every launch, else the per-step call indices to bracket
+
+    def _skip():
+        i = sel["idx"]
+        sel["idx"] = i + 1
+        return sel["calls"] is not None and i not in sel["calls"]
+
     def timed_conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0, res_upsample=False, **kw):
+        if _skip():
+            return orig_conv2d(x, pc, residual=residual, relu=relu, out=out, variant=variant, c_off=c_off, res_upsample=res_upsample, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         y = orig_conv2d(x, pc, residual=residual, relu=relu, out=out, variant=variant, c_off=c_off, res_upsample=res_upsample, **kw)
@@ -104,6 +117,8 @@ def main():
     orig_conv2d_head = nn_ops.conv2d_head
 
     def timed_conv2d_head(x, pc, pc2, variant=None):
+        if _skip():
+            return orig_conv2d_head(x, pc, pc2, variant=variant)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         y = orig_conv2d_head(x, pc, pc2, variant=variant)
@@ -121,6 +136,7 @@ def main():
         pre_mat = torch.tensor([1.0, 0, 0, 0, 1.0, 0], dtype=torch.float32, device=dev).repeat(B, 1).contiguous()
 
     def step():
+        sel["idx"] = 0
         x = images
         if images_u8 is not None:
             x = nn_ops.image_preprocess(images_u8, pre_mat, (0.408, 0.447, 0.470), (0.289, 0.274, 0.278), (H, W),
@@ -133,9 +149,25 @@ def main():
             return gather_detections(dets, count, force=True)
         return dets, count
 
-    for _ in range(args.warmup):
-        step()
     instrument = not args.no_roofline
+    survey = None          # records of ONE fully bracketed step (the last warmup step): the whole-set table in --bracket dominant
+    dominant_only = instrument and args.bracket == "dominant" and args.warmup >= 1 and not args.dump_convs
+    for w_i in range(args.warmup):
+        if dominant_only and w_i == args.warmup - 1:
+            nn_ops.conv2d, nn_ops.conv2d_head = timed_conv2d, timed_conv2d_head
+            step()
+            nn_ops.conv2d, nn_ops.conv2d_head = orig_conv2d, orig_conv2d_head
+            torch.cuda.synchronize()
+            survey = list(records)
+            del records[:]
+        else:
+            step()
+    if dominant_only and survey:
+        t_k = {}
+        for r in survey:
+            t_k[r[7]] = t_k.get(r[7], 0.0) + r[0].elapsed_time(r[1])
+        dom_id = max(t_k, key=t_k.get)
+        sel["calls"] = frozenset(i for i, r in enumerate(survey) if r[7] == dom_id)   # dispatch is deterministic per call site
     if instrument:
         nn_ops.conv2d = timed_conv2d
         nn_ops.conv2d_head = timed_conv2d_head
@@ -158,23 +190,33 @@ def main():
 
     roofline = None
     if instrument and records:
-        ms = [e0.elapsed_time(e1) for e0, e1, *_ in records]
+        # whole conv/FC set: every launch of the timed region (--bracket all) or of the fully bracketed last warmup step
+        all_recs, all_steps = (survey, 1) if survey else (records, max(args.steps, 1))
+        ms = [e0.elapsed_time(e1) for e0, e1, *_ in all_recs]
         tot_ms = sum(ms)
-        tot_fl = sum(r[2] for r in records)
+        tot_fl = sum(r[2] for r in all_recs)
         # per kernel; the DOMINANT one (most time) fills the contract fields, the whole conv/FC set goes to "all_conv"
         per_k = {}
-        for r, t_ms in zip(records, ms):
+        for r, t_ms in zip(all_recs, ms):
             d = per_k.setdefault(r[7], [0.0, 0.0, 0.0, 0])
             d[0] += t_ms; d[1] += r[2]; d[2] += r[6]; d[3] += 1
         dom = max(per_k, key=lambda k_: per_k[k_][0])
-        d_ms, d_fl, d_by, d_n = per_k[dom]
+        dom_share = per_k[dom][0] / tot_ms
+        # the dominant kernel's figures always come from the TIMED region's events
+        d_ms = d_fl = d_by = 0.0
+        d_n = 0
+        for r in records:
+            if r[7] == dom:
+                d_ms += r[0].elapsed_time(r[1]); d_fl += r[2]; d_by += r[6]; d_n += 1
+        if d_n == 0:
+            raise RuntimeError("bench: the dominant kernel of the bracketed warmup step was not launched in the timed region")
         # which roofline binds the dominant kernel's launches in aggregate: HBM (algorithmic bytes / 8 TB/s) or MFMA
         # (algorithmic flops / 2.5 PFLOP/s dense bf16)
         hbm_bound = d_by / PEAK_HBM_BPS > d_fl / (PEAK_BF16_TFLOPS * 1e12)
         ach = d_by / (d_ms * 1e-3) / 1e9 if hbm_bound else d_fl / (d_ms * 1e-3) / 1e12
         peak = PEAK_HBM_BPS / 1e9 if hbm_bound else PEAK_BF16_TFLOPS
         # layer-wise roofline: each launch is bounded by max(flops / MFMA peak, algorithmic bytes / HBM peak)
-        t_roof_ms = sum(max(r[2] / (PEAK_BF16_TFLOPS * 1e12), r[6] / PEAK_HBM_BPS) for r in records) * 1e3
+        t_roof_ms = sum(max(r[2] / (PEAK_BF16_TFLOPS * 1e12), r[6] / PEAK_HBM_BPS) for r in all_recs) * 1e3
         traffic = all_traffic = None
         tp = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
         PMC_PREFIX = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<256, 2, 2, 2, 2, 2,"}  # all instantiations of the kernel
@@ -186,7 +228,9 @@ def main():
                 if sel:
                     traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / sum(v["launches"] for v in sel) / 1e6, 2)
         roofline = {"bound": "hbm" if hbm_bound else "mfma",
-                    "kernel": KNAMES.get(dom, str(dom)) + " (dominant kernel: %.0f %% of the conv/FC time)" % (100 * d_ms / tot_ms),
+                    "kernel": KNAMES.get(dom, str(dom)) + " (dominant kernel: %.0f %% of the conv/FC time)" % (100 * dom_share),
+                    "bracketed": "HIP events around this kernel's launches in the timed region" + (
+                        "; all_conv: every launch of the last warmup step" if survey else "; all_conv: every launch of the timed region"),
                     "achieved": round(ach, 2), "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_unit": "MB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_conv_traffic.json)",
                     "achieved_tflops": round(d_fl / (d_ms * 1e-3) / 1e12, 2),
@@ -194,19 +238,19 @@ def main():
                     "algorithmic_gflop_per_launch": round(d_fl / d_n / 1e9, 1),
                     "launches_per_step": d_n // max(args.steps, 1),
                     "avg_launch_us": round(d_ms * 1e3 / d_n, 2),
-                    "all_conv": {"kernels": {KNAMES.get(k_, str(k_)): {"ms_per_step": round(v[0] / max(args.steps, 1), 3),
+                    "all_conv": {"kernels": {KNAMES.get(k_, str(k_)): {"ms_per_step": round(v[0] / all_steps, 3),
                                                                        "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1),
-                                                                       "launches_per_step": v[3] // max(args.steps, 1)}
+                                                                       "launches_per_step": v[3] // all_steps}
                                              for k_, v in sorted(per_k.items())},
                                  "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                                  "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                                  "frac_of_layerwise_roofline": round(t_roof_ms / tot_ms, 4),
                                  "traffic_mb_per_launch": all_traffic,
-                                 "algorithmic_mb_per_launch": round(sum(r[6] for r in records) / len(records) / 1e6, 2),
-                                 "launches_per_step": len(records) // max(args.steps, 1),
-                                 "avg_launch_us": round(tot_ms * 1e3 / len(records), 2),
-                                 "conv_ms_per_step": round(tot_ms / max(args.steps, 1), 3),
-                                 "algorithmic_gflop_per_step": round(tot_fl / max(args.steps, 1) / 1e9, 1)}}
+                                 "algorithmic_mb_per_launch": round(sum(r[6] for r in all_recs) / len(all_recs) / 1e6, 2),
+                                 "launches_per_step": len(all_recs) // all_steps,
+                                 "avg_launch_us": round(tot_ms * 1e3 / len(all_recs), 2),
+                                 "conv_ms_per_step": round(tot_ms / all_steps, 3),
+                                 "algorithmic_gflop_per_step": round(tot_fl / all_steps / 1e9, 1)}}
 
     if args.dump_convs and rank == 0 and records:
         per = {}
