@@ -3,7 +3,7 @@ The oracle's detections (fp32 torch-CPU restatement of the same graph, same rand
 taken as ground truth and the device detections are scored against them with the COCO bbox protocol (minddet_amd/coco_eval.py):
 AP 1.0 = every oracle box is found with IoU >= 0.95 and nothing else ranks above it.  `quant` = the oracle rounds activations and
 weights to bf16 where the device stores bf16 (isolates kernel arithmetic from storage precision).
-usage: python tools/agreement_ap.py [config] [batch]"""
+Lives under tests/ because it drives the oracle (test infrastructure).  usage: python tests/agreement_ap.py [config] [batch]"""
 import os, sys
 import numpy as np
 import torch

@@ -179,14 +179,10 @@ def test_full_size_structural_properties():
 
 def test_end_to_end_agreement_in_map_units():
     """The whole device path against the whole CPU oracle (independent runs, nothing shared at stage boundaries): the oracle's
-    detections are the ground truth of a COCO bbox evaluation of the device detections (tools/agreement_ap.py).  Random-init
+    detections are the ground truth of a COCO bbox evaluation of the device detections (tests/agreement_ap.py).  Random-init
     weights make every score margin tiny, so a bf16 rounding can swap ranks or NMS survivors; measured r01: AP 0.98 against the
     oracle that rounds to bf16 where the device stores bf16, 0.85 against the pure fp32 oracle.  Bounds leave room for box variance."""
-    import os
-    import sys
-
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    import agreement_ap
+    from tests import agreement_ap
 
     r = agreement_ap.agreement()
     assert r["bf16-matched oracle"]["n_oracle"] > 20
