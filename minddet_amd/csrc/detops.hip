@@ -199,7 +199,7 @@ __device__ void topk_block_select(const float *__restrict__ scores, const int *_
                                   float min_score, float *__restrict__ out_val, int *__restrict__ out_idx,
                                   int *__restrict__ out_cnt, unsigned long long *sel /* LDS, TOPK_MAXK entries */) {
     __shared__ unsigned hist[256];
-    __shared__ unsigned s_prefix, s_remaining, s_count, s_wave_base[TOPK_THREADS / 64], s_tie_taken;
+    __shared__ unsigned s_prefix, s_remaining, s_count, s_wave_base[TOPK_THREADS / 64], s_tie_taken, s_tie_total;
     const int tid = threadIdx.x;
     const int beg = seg_off[seg], n = seg_off[seg + 1] - beg;
     const float *sc = scores + beg;
@@ -257,37 +257,60 @@ __device__ void topk_block_select(const float *__restrict__ scores, const int *_
     }
     const unsigned thr = prefix;  // exact ordinal of the kk-th largest (or omin)
 
-    // compaction: strictly-greater elements in any order
-    if (tid == 0) { s_count = 0; s_tie_taken = 0; }
+    // compaction, part 1: strictly-greater elements in any order; count the copies of the k-th value
+    if (tid == 0) { s_count = 0; s_tie_taken = 0; s_tie_total = 0; }
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {
-        const int i = i0 + tid;
-        const unsigned u = i < n ? ford(sc[i]) : 0u;
-        const bool gt = i < n && u > omin && u > thr;
-        const bool tie = i < n && u > omin && u == thr && remaining > 0;
-        if (gt) {
-            const unsigned pos = atomicAdd(&s_count, 1u);
-            if (pos < (unsigned)TOPK_MAXK) sel[pos] = ((unsigned long long)(~u) << 32) | (unsigned)i;
+    {
+        unsigned ties = 0;
+        for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {
+            const int i = i0 + tid;
+            const unsigned u = i < n ? ford(sc[i]) : 0u;
+            if (i < n && u > omin && u > thr) {
+                const unsigned pos = atomicAdd(&s_count, 1u);
+                if (pos < (unsigned)TOPK_MAXK) sel[pos] = ((unsigned long long)(~u) << 32) | (unsigned)i;
+            }
+            ties += (i < n && u > omin && u == thr && remaining > 0) ? 1u : 0u;
         }
-        // ties: ordered (index-ascending) selection of the first `remaining`
-        const unsigned long long bal = __ballot(tie);
-        const int wv = tid >> 6, ln = tid & 63;
-        if (ln == 0) s_wave_base[wv] = (unsigned)__popcll(bal);
-        __syncthreads();
-        if (tid == 0) {
-            unsigned run = s_tie_taken;
-            for (int w = 0; w < TOPK_THREADS / 64; ++w) { const unsigned c = s_wave_base[w]; s_wave_base[w] = run; run += c; }
-            s_tie_taken = run;
-        }
-        __syncthreads();
-        if (tie) {
-            const unsigned rank = s_wave_base[wv] + (unsigned)__popcll(bal & ((1ull << ln) - 1ull));
-            if (rank < remaining) {
-                const unsigned pos = (unsigned)kk - remaining + rank;  // ties live at the tail
+        for (int o = 32; o > 0; o >>= 1) ties += __shfl_xor(ties, o, 64);
+        if ((tid & 63) == 0 && ties) atomicAdd(&s_tie_total, ties);
+    }
+    __syncthreads();
+    // part 2: copies of the k-th value.  When exactly the missing number exists they are all taken, in any order (the sort below
+    // orders by (value, index)): no barriers.  r01: the barrier-per-1024-elements ordered scan used to run for every segment --
+    // 48 barriers on the 16 384-element CenterNet maps.  It is needed only when the k-th value has more copies than are missing.
+    if (remaining > 0 && s_tie_total == remaining) {
+        for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {
+            const int i = i0 + tid;
+            const unsigned u = i < n ? ford(sc[i]) : 0u;
+            if (i < n && u > omin && u == thr) {
+                const unsigned pos = (unsigned)kk - remaining + atomicAdd(&s_tie_taken, 1u);
                 sel[pos] = ((unsigned long long)(~u) << 32) | (unsigned)i;
             }
         }
-        __syncthreads();
+    } else if (remaining > 0) {
+        // ordered (index-ascending) selection of the first `remaining` copies; stops (uniformly) once they are found
+        for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {
+            const int i = i0 + tid;
+            const unsigned u = i < n ? ford(sc[i]) : 0u;
+            const bool tie = i < n && u > omin && u == thr;
+            const unsigned long long bal = __ballot(tie);
+            const int wv = tid >> 6, ln = tid & 63;
+            if (ln == 0) s_wave_base[wv] = (unsigned)__popcll(bal);
+            __syncthreads();
+            if (tid == 0) {
+                unsigned run = s_tie_taken;
+                for (int w = 0; w < TOPK_THREADS / 64; ++w) { const unsigned c = s_wave_base[w]; s_wave_base[w] = run; run += c; }
+                s_tie_taken = run;
+            }
+            __syncthreads();
+            if (tie) {
+                const unsigned rank = s_wave_base[wv] + (unsigned)__popcll(bal & ((1ull << ln) - 1ull));
+                if (rank < remaining) sel[(unsigned)kk - remaining + rank] = ((unsigned long long)(~u) << 32) | (unsigned)i;
+            }
+            const bool done = s_tie_taken >= remaining;   // every thread reads the same value between the two barriers
+            __syncthreads();
+            if (done) break;
+        }
     }
     // (greater elements occupy [0, kk-remaining), ties [kk-remaining, kk))
     // bitonic sort ascending on (~key, idx)  == key descending, index ascending
