@@ -1461,7 +1461,8 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     // 3x3 layers on <= 256 channels: the 64-cout halo-reuse kernel at four workgroups per CU beats the 128x128 kernel wherever
     // the ping-pong kernel does not apply, and beats the ping-pong kernel when its 256x256 tiles fill the last of several rounds
     // badly (r01 tools/conv_ab_yolo.py, batch 32: 128->128 @80x80 +11 %, 256->256 @20x20 +16 %, 256->256 @80x80 (3.1 rounds) +8 %;
-    // one-round grids and K = 4608 layers stay where they were)
+    // one-round grids and K = 4608 layers stay where they were -- except Cout not a multiple of 128, where the 128x128 kernel pads:
+    // 512->320 @40x40 +23 %, tools/dispatch_audit.py)
     const long long pp_rounds = (pp_blocks + 255) / 256;
     const bool pp_ragged = pp_rounds >= 2 && (double)pp_blocks < 0.85 * (double)(pp_rounds * 256);
     // ... provided its 8x16-pixel tiles cover the image without much waste (100x168: 8 % idle lanes and the 128x128 kernel is 3 %
@@ -1471,7 +1472,8 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     const bool cat_only_h = !a.adv || (a.os == 1 && a.oy == 0 && a.ox == 0 && a.Ho == a.Hf && a.Wo == a.Wf && a.pad_top == a.pad &&
                                        a.pad_left == a.pad && (!a.res || a.Rs));
     const bool halo64_first = variant == 0 && !head && dma_ok && cat_only_h && a.korder == 1 && a.kh == 3 && a.kw == 3 && a.stride == 1 &&
-                              a.pad == 1 && a.Cin % 64 == 0 && a.Cin <= 256 && a.Cout % 64 == 0 && cout_pad % 64 == 0 && !a.res_up &&
+                              a.pad == 1 && a.Cin % 64 == 0 && (a.Cin <= 256 || (a.Cin <= 512 && a.Cout % 128 != 0)) && a.Cout % 64 == 0 &&
+                              cout_pad % 64 == 0 && !a.res_up &&
                               a.Ho == a.H && a.Wo == a.W && (!pp_ok || pp_ragged) && halo_fits;
     if (halo64_first) return launch_conv3x3_halo<64, true>(a, s);
     if (variant == 0 && pp_ok) return launch_conv_pingpong<0>(a, s);
