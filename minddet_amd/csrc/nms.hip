@@ -133,6 +133,19 @@ __global__ __launch_bounds__(256) void nms_normal7_mask_kernel(const float *__re
     }
 }
 
+// does row box a (kept, higher score) suppress column box c?
+__device__ __forceinline__ bool aligned_suppresses(const float *a, const float4 c, float area_c, float off, int mode, float thr) {
+    const float ax1 = a[0], ay1 = a[1], ax2 = a[2], ay2 = a[3];
+    const float area_a = (ax2 - ax1 + off) * (ay2 - ay1 + off);
+    const float w = rhi(rlo(ax2, c.z) - rhi(ax1, c.x) + off, 0.0f);
+    const float h = rhi(rlo(ay2, c.w) - rhi(ay1, c.y) + off, 0.0f);
+    const float inter = w * h;
+    float ovr;
+    if (mode == 2) ovr = inter / fmaxf(area_a + area_c - inter, ROT_EPS);
+    else ovr = inter / (area_a + area_c - inter);
+    return mode == 0 ? (ovr >= thr) : (ovr > thr);
+}
+
 // corner boxes [x1,y1,x2,y2]; modes documented in minddet_hip.h (md_nms_attrs)
 __global__ __launch_bounds__(256) void nms_aligned_mask_kernel(const float *__restrict__ boxes_all,
                                                                 const int *__restrict__ count,
@@ -166,17 +179,8 @@ __global__ __launch_bounds__(256) void nms_aligned_mask_kernel(const float *__re
         const int gr = rb * TILE + rr;
         if (gr >= n) break;
         bool pred = false;
-        if (gc < n && (cbk != rb || lane > rr) && row_grp[rr] == cg) {
-            const float ax1 = row_box[rr * 4], ay1 = row_box[rr * 4 + 1], ax2 = row_box[rr * 4 + 2], ay2 = row_box[rr * 4 + 3];
-            const float area_a = (ax2 - ax1 + off) * (ay2 - ay1 + off);
-            const float w = rhi(rlo(ax2, c.z) - rhi(ax1, c.x) + off, 0.0f);
-            const float h = rhi(rlo(ay2, c.w) - rhi(ay1, c.y) + off, 0.0f);
-            const float inter = w * h;
-            float ovr;
-            if (mode == 2) ovr = inter / fmaxf(area_a + area_c - inter, ROT_EPS);
-            else ovr = inter / (area_a + area_c - inter);
-            pred = mode == 0 ? (ovr >= thr) : (ovr > thr);
-        }
+        if (gc < n && (cbk != rb || lane > rr) && row_grp[rr] == cg)
+            pred = aligned_suppresses(row_box + rr * 4, c, area_c, off, mode, thr);
         const unsigned long long w64 = __ballot(pred);
         if (lane == 0) mask[(size_t)gr * cb + cbk] = w64;
     }

@@ -233,3 +233,30 @@ def test_rotate_iou_eval_vs_oracle(criterion):
         q7 = np.zeros((k, 7), np.float32); q7[:, [0, 1, 3, 4]] = q[:, :4]; q7[:, 6] = -q[:, 4]
         ov = oracle.boxes_overlap_bev(b7, q7)
         assert np.abs(got - ov).max() < 5e-2   # MARGIN 1e-2 of check_in_box2d only affects grazing contacts
+
+
+@pytest.mark.parametrize("cfg", [(9, 1000, 100, 0.5, 3), (32, 4096, 300, 0.45, 80), (8, 257, 64, 0.7, 1), (12, 640, 20, 0.3, 5)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_quota_nms_batched_equals_list_by_list(cfg, mode):
+    """md_nms_aligned with an output quota, ragged counts and class-keyed groups: a batch of lists gives, list by list, the keep
+    masks, kept indices and counts of single-list calls.  (Written for a matrix-free quota kernel that was measured and dropped --
+    DESIGN.md section 9 -- and kept as a consistency test of the batched path.)  Clustered boxes so that suppression happens."""
+    from minddet_amd import det_ops
+
+    L, n, quota, thr, ngroups = cfg
+    rng = np.random.default_rng(L * n + mode)
+    centers = rng.uniform(50, 600, (L, 40, 2)).astype(np.float32)
+    pick = rng.integers(0, 40, (L, n))
+    c = np.take_along_axis(centers, np.repeat(pick[..., None], 2, 2), 1) + rng.normal(0, 6, (L, n, 2)).astype(np.float32)
+    wh = rng.uniform(20, 80, (L, n, 2)).astype(np.float32)
+    boxes = np.concatenate([c - wh / 2, c + wh / 2], -1).astype(np.float32)
+    count = rng.integers(n // 2, n + 1, L).astype(np.int32)
+    count[0] = n
+    group = rng.integers(0, ngroups, (L, n)).astype(np.int32)
+    bt, ct, gt = torch.from_numpy(boxes).to(DEV), torch.from_numpy(count).to(DEV), torch.from_numpy(group).to(DEV)
+    keep, kidx, num = det_ops.nms_aligned(bt, thr, mode=mode, count=ct, group=gt, max_output=quota)
+    assert int(num.max()) <= quota and int(num.min()) > 0
+    for l in range(L):
+        k1, i1, n1 = det_ops.nms_aligned(bt[l:l + 1], thr, mode=mode, count=ct[l:l + 1], group=gt[l:l + 1], max_output=quota)
+        assert int(n1[0]) == int(num[l])
+        assert torch.equal(k1[0], keep[l]) and torch.equal(i1[0, : int(n1[0])], kidx[l, : int(num[l])])
