@@ -35,6 +35,11 @@ CASES = [
     ("pp_3x3_s2_128_256", 1, 51, 85, 128, 256, 3, 2, 1, True, False, True),
     ("halo64_128_64_res", 2, 19, 37, 128, 64, 3, 1, 1, True, True, True),
     ("halo64_192_192", 1, 24, 33, 192, 192, 3, 1, 1, True, False, False),
+    ("c32_3x3", 2, 40, 44, 32, 64, 3, 1, 1, True, False, True),
+    ("c32_3x3_s2_res", 1, 41, 37, 32, 32, 3, 2, 1, True, True, True),
+    ("c32_1x1", 2, 20, 24, 32, 128, 1, 1, 0, False, False, False),
+    ("c32_4x4_16_taps", 1, 18, 22, 32, 40, 4, 2, 1, True, False, False),
+    ("c32_5x5_generic", 1, 18, 22, 32, 32, 5, 1, 2, True, False, False),
 ]
 
 
