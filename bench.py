@@ -44,6 +44,9 @@ def main():
                     help="which conv launches of the TIMED region are bracketed by HIP events: only the dominant kernel's (default: "
                          "the whole-set table then comes from the last warmup step, where every launch is bracketed; 2 events per "
                          "launch cost ~1.5 %% of the step when all 68 launches carry them) or all of them")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step in a HIP graph and replay it (minddet_amd/replay.py): pays off only where the path is "
+                         "launch-bound (small batches); implies --no-roofline (events cannot bracket launches inside a graph)")
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "faster_rcnn", "faster_rcnn_r50_fpn.py"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -149,6 +152,14 @@ def main():
             return gather_detections(dets, count, force=True)
         return dets, count
 
+    if args.graph:
+        if use_dist or images_u8 is not None:
+            raise SystemExit("bench.py --graph: single-GPU, pre-processed input only")
+        from minddet_amd.replay import CapturedStep
+
+        args.no_roofline = True
+        captured = CapturedStep(lambda xx: tuple(model.forward(xx))[:2], images)
+        step = lambda: captured(images)   # noqa: E731
     instrument = not args.no_roofline
     survey = None          # records of ONE fully bracketed step (the last warmup step): the whole-set table in --bracket dominant
     dominant_only = instrument and args.bracket == "dominant" and args.warmup >= 1 and not args.dump_convs

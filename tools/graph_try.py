@@ -1,4 +1,4 @@
-"""Try capturing one detector step in a HIP graph (torch.cuda.CUDAGraph) and replaying it."""
+"""Try capturing one detector step in a HIP graph (torch.cuda.CUDAGraph) and replaying it.  python tools/graph_try.py [batch] [config]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,16 +8,18 @@ from minddet_amd.data import synthetic_images
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device("cuda", 0)
-cfg = Config.fromfile("configs/faster_rcnn/faster_rcnn_r50_fpn.py")
+cfg = Config.fromfile(sys.argv[2] if len(sys.argv) > 2 else "configs/faster_rcnn/faster_rcnn_r50_fpn.py")
 model = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(dev)
 H, W = cfg.data.input_hw
-images = nn_ops.to_stem_layout(synthetic_images(B, H, W, device=dev))
+images = synthetic_images(B, H, W, device=dev)
+if type(model).__name__ in ("FasterRCNN", "MaskRCNN"):
+    images = nn_ops.to_stem_layout(images)
 for _ in range(3):
-    dets, count = model.forward(images)
+    dets, count = model.forward(images)[:2]
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(10):
-    dets, count = model.forward(images)
+    dets, count = model.forward(images)[:2]
 torch.cuda.synchronize()
 t_eager = (time.perf_counter() - t0) / 10
 s = torch.cuda.Stream()
@@ -28,7 +30,7 @@ with torch.cuda.stream(s):
 torch.cuda.current_stream().wait_stream(s)
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
-    gd, gc = model.forward(images)
+    gd, gc = model.forward(images)[:2]
 torch.cuda.synchronize()
 g.replay()
 torch.cuda.synchronize()
