@@ -30,6 +30,29 @@ def test_empty_inputs_are_ok():
     assert out.shape == (0, 7, 7, 16)
 
 
+def test_empty_batches_through_the_newer_ops():
+    """Zero images / zero cells through the fused heat-map op, the YOLO decodes, the chained conv and the channel-slice conv."""
+    from minddet_amd import det_ops, nn_ops
+
+    bf = dict(dtype=torch.bfloat16, device=DEV)
+    heat, hm = det_ops.heat_peaks(torch.zeros((0, 16, 16, 88), **bf), 0, 80, with_hm=True)
+    assert heat.shape == (0, 80, 16, 16) and hm.shape == heat.shape
+    boxes = torch.zeros((0, 48, 4), device=DEV)
+    scores, labels = torch.zeros((0, 48), device=DEV), torch.zeros((0, 48), dtype=torch.int32, device=DEV)
+    det_ops.yolo_decode(torch.zeros((0, 4, 4, 256), **bf), boxes, scores, labels, 80, 3, 8.0, [10, 13, 16, 30, 33, 23], 0.25, 0, 48)
+    boxes8 = torch.zeros((0, 16, 4), device=DEV)
+    det_ops.yolov8_decode(torch.zeros((0, 4, 4, 144), **bf), boxes8, torch.zeros((0, 16), device=DEV),
+                          torch.zeros((0, 16), dtype=torch.int32, device=DEV), 80, 16, 8.0, 0.25, 0, 16)
+    pc = nn_ops.pack_conv(torch.randn((256, 64, 1, 1)) * 0.1, relu=True).to(DEV)
+    pc2 = nn_ops.pack_conv(torch.randn((64, 256, 1, 1)) * 0.1, relu=True).to(DEV)
+    y, y2 = nn_ops.conv2d_chain(torch.zeros((0, 8, 8, 64), **bf), pc, pc2)
+    assert y.shape == (0, 8, 8, 256) and y2.shape == (0, 8, 8, 64)
+    pc3 = nn_ops.pack_conv(torch.randn((64, 64, 3, 3)) * 0.1, pad=1).to(DEV)
+    z = nn_ops.conv2d(torch.zeros((0, 8, 8, 192), **bf), pc3, x_c_off=64)
+    assert z.shape == (0, 8, 8, 64)
+    torch.cuda.synchronize()
+
+
 def test_degenerate_boxes_do_not_crash():
     from minddet_amd import det_ops
 
