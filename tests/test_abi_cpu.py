@@ -52,3 +52,25 @@ def test_product_never_imports_oracle():
     # bench.py may use it in its cpu_baseline leg only, __graft_entry__.py in build() / smoke() only
     bench = open(os.path.join(ROOT, "bench.py")).read()
     assert len(pat.findall(bench)) == 1 and bench.index("cpu_baseline = None") < pat.search(bench).start()
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """profiles/r01_final_bench.json is the bench.py line of the profiled run: the driver's contract fields, the roofline object and the
+    cpu_baseline object must all be there (a schema regression in bench.py shows up when the profile is regenerated)."""
+    import json
+
+    line = open(os.path.join(ROOT, "profiles", "r01_final_bench.json")).read().strip().splitlines()[-1]
+    j = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "bf16"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port")
