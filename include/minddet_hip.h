@@ -135,8 +135,9 @@ typedef struct md_conv2d_attrs {
                                     1 register-staged 128x128, 2 / 20 LDS-DMA 128x128 with two / one staging buffer,
                                     5 128x128 on 16x16x32 MFMA, 11 / 27 halo-reuse kernel with 128- / 64-cout tiles,
                                     15 / 22 256x256 ping-pong kernel (32x32x16 / 16x16x32 MFMA); a variant whose
-                                    preconditions do not hold falls back to the generic kernel.  17-19 and 25 are timing /
-                                    stamp diagnostics (tools/pp_stamps.py, tools/igemm_stamps.py) and do NOT compute the convolution. */
+                                    preconditions do not hold falls back to the generic kernel.  17-19 and 25 (timing /
+                                    stamp diagnostics that do NOT compute the convolution) exist only in the MD_DIAG build
+                                    used by tools/ (libminddet_hip_diag.so); this library rejects them with MD_ERR_ARG. */
     /* generalised addressing, used when adv != 0 (all zero = plain conv).  The op then computes, for
      * ho < sub_h, wo < sub_w:  y[n, ho*out_stride + out_off_y, wo*out_stride + out_off_x, c_off + c] =
      * act(bias[c] + sum x[n, ho*stride - pad_top + kh, wo*stride - pad_left + kw, ci] * w[c,kh,kw,ci]), c < cout.
@@ -156,7 +157,7 @@ typedef struct md_conv2d_attrs {
                                     the packed weights are for Cin = x_cin) */
     int32_t res_slice, res_c_off;/* res_slice != 0: residual is [N,Ho,Wo,R] and channels [res_c_off, res_c_off + Cout) are added
                                     (res_c_off % 8 == 0; unit output stride, no res_upsample) */
-    int32_t chain_relu;          /* md_conv2d_chain only: ReLU on the chained (second) conv */
+    int32_t reserved0;           /* must be 0 */
 } md_conv2d_attrs;
 /* Replaces Conv2d -> BatchNorm2d(eval) -> [+ residual] -> ReLU of the reference graphs
  * (centernet/src/resnet.py:109-178,181-252; centerpoint/det3d_ms/models/necks/rpn.py:9-154).
@@ -179,17 +180,6 @@ int md_conv2d_cout_tile(int cout);
  * out: y2[N,Ho,Wo,16] bf16 ; optional trailing workspace (N*Ho*Wo*512 bytes, used only by the two-launch path)
  * extra: md_conv2d_attrs of the FIRST conv (relu must be 1, plain addressing). */
 int md_conv2d_head(MD_AOT_ARGS);
-
-/* The bottleneck's expand conv chained into the next block's reduce conv (centernet/src/resnet.py:139-178, two consecutive
- * Bottleneck cells: conv3 + bn3 + residual + relu of block i, conv1 + bn1 + relu of block i+1): y = act(conv1x1(x) + residual)
- * with 256 output channels AND y2 = act2(conv1x1(y)) with 64 or 128 channels in ONE launch -- y2 is computed from the output
- * tile while it is still in LDS, so the 256-channel tensor is not re-read from HBM.  Same results as two md_conv2d calls
- * (which is also the fallback for any other shape).
- * in : x[N,H,W,Cin] bf16, w[256,Kpad] bf16, bias[256] f32, residual[N,H,W,256] bf16 | NULL
- * out: y[N,H,W,256] bf16
- * in : w2[C2pad,256] bf16, bias2[C2pad] f32      out: y2[N,H,W,C2] bf16
- * extra: md_conv2d_attrs of the first conv (kh = kw = 1, stride 1, pad 0) + chain_relu. */
-int md_conv2d_chain(MD_AOT_ARGS);
 
 /* Which kernel the dispatcher launched for the calling host thread's most recent md_conv2d (0 before any call, or when
  * the call returned without launching).  Diagnostic only: lets bench.py attribute per-launch HIP-event timings. */

@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libminddet_hip.so")
+# MD_DIAG_LIB=1 (tools/pp_stamps.py, tools/igemm_stamps.py only): the -DMD_DIAG build with the timing ablations and stamp kernels
+LIB_PATH = os.path.join(_HERE, "libminddet_hip_diag.so" if os.environ.get("MD_DIAG_LIB") == "1" else "libminddet_hip.so")
 _lib = None
 
 _DT = {

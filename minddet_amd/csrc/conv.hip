@@ -33,6 +33,16 @@
 
 namespace md {
 
+// MD_DIAG (tools/ only: `make -C minddet_amd/csrc diag` -> libminddet_hip_diag.so): the timing ablations and in-kernel stamps of
+// tools/pp_stamps.py / igemm_stamps.py.  They do not compute the convolution, so the PRODUCT library neither contains them
+// nor accepts their variant ids (md_conv2d returns MD_ERR_ARG); stamps go to a buffer of their own (md_diag_set_stamp_buffer),
+// never into an output tensor.
+#ifdef MD_DIAG
+constexpr bool kDiag = true;
+#else
+constexpr bool kDiag = false;
+#endif
+
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -65,11 +75,10 @@ struct ConvArgs {
     uint16_t *y2;           // [N,Ho,Wo,16] bf16 -- the ONLY tensor a HEAD launch writes
     int pointwise;          // 1x1 / stride 1 / pad 0 (input pixel index == output pixel index)
     int bias_lds_off;       // byte offset of the CT-float bias copy in LDS (past the staging buffers and the epilogue image)
-    int stamp;              // diagnostic (variant 25): a mid-grid workgroup overwrites the first output bytes with s_memtime stamps
+    int stamp;              // MD_DIAG builds only (variant 25): a mid-grid workgroup writes its cycle stamps to a.dbg
+    unsigned long long *dbg; // MD_DIAG builds only: the stamp buffer (md_diag_set_stamp_buffer), never an output tensor
     int res_up;             // 1: residual is [N, ceil(Ho/2), ceil(Wo/2), Cout], read with nearest 2x upsampling
                             //    (the FPN top-down add fused into the lateral 1x1 conv); plain addressing only
-    int c2;                 // chained 1x1 conv (conv_igemm_kernel<.., CHAIN>): its output channels (64 or 128); w2 [>= c2][256], b2, y2
-    int relu2;              // ReLU on the chained conv's output
     int Xs;                 // pixel stride of x in channels (== Cin unless the input is a channel slice of a wider tensor;
                             // a.x then already points at the slice's first channel)
     int Rs;                 // 0: the residual has the output's layout; > 0: residual pixel m, channel c at m*Rs + c (a channel
@@ -139,11 +148,8 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 
 // instantiations for ReLU-or-none / SiLU layers whose output is a whole tensor or a channel range of a concat buffer
 // (offset = m * Ctot + c_off + c): the division-heavy address code of the general epilogue is compiled out (it was 2/3 of the
 // kernel's instructions) and the activation is a compile-time choice.
-// CHAIN 1 / 2 (CT = 256 = all output channels of the layer, PT = 64): the NEXT layer's 1x1 conv (256 -> 64 / 128 channels, + bias
-// [+ ReLU]) is computed from the finished output tile while it is still in LDS -- the bottleneck's expand conv (+ residual + ReLU)
-// chained into the following block's reduce conv, whose 256-channel input is then never re-read from HBM.
-template <int NT, int WC, int WP, int FC, int FP, int MODE, int MF = 0, int GEN = 1, int CHAIN = 0>
-__global__ __launch_bounds__(NT, NT == 256 ? (CHAIN ? 4 : 3) : 2) void conv_igemm_kernel(ConvArgs a) {
+template <int NT, int WC, int WP, int FC, int FP, int MODE, int MF = 0, int GEN = 1>
+__global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr bool GLDS = MODE != 0;
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
     constexpr int RPP = NT / 8;                            // tile rows staged per pass of the workgroup
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? (CHAIN ? 4 : 3) : 2) void conv_igem
     if (pt >= a.n_ptiles) return;
     const int cout0 = ct * CT, pix0 = pt * PT;
     unsigned long long stp[6] = {0, 0, 0, 0, 0, 0};
-    if (a.stamp) stp[0] = __builtin_readcyclecounter();
+    if (kDiag && a.stamp) stp[0] = __builtin_readcyclecounter();
     // The tile's bias is requested NOW and parked in LDS for the epilogue.  r01 stamps (tools/igemm_stamps.py): fetched
     // after the K loop, this one dependent global load exposed 9-12k cycles of loaded-HBM latency in every workgroup.
     const float bias_early = tid < CT ? a.bias[cout0 + tid] : 0.f;
@@ -381,11 +387,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? (CHAIN ? 4 : 3) : 2) void conv_igem
                 dma_tile(kt, 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (a.stamp && kt == 0) stp[1] = __builtin_readcyclecounter();
+                if (kDiag && a.stamp && kt == 0) stp[1] = __builtin_readcyclecounter();
                 compute_tile(0);
                 __syncthreads();
             }
-            if (a.stamp) stp[2] = __builtin_readcyclecounter();
+            if (kDiag && a.stamp) stp[2] = __builtin_readcyclecounter();
         } else {
         dma_tile(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
@@ -495,9 +501,9 @@ __global__ __launch_bounds__(NT, NT == 256 ? (CHAIN ? 4 : 3) : 2) void conv_igem
             }
         }
     }
-    if (a.stamp) stp[3] = __builtin_readcyclecounter();
+    if (kDiag && a.stamp) stp[3] = __builtin_readcyclecounter();
     __syncthreads();
-    if (a.stamp) stp[4] = __builtin_readcyclecounter();
+    if (kDiag && a.stamp) stp[4] = __builtin_readcyclecounter();
     // ---- coalesced NHWC store: 16 B (8 couts) per lane, CT/8 lanes per pixel
 #pragma unroll
     for (int it = 0; it < EP_ITERS; ++it) {
@@ -518,79 +524,14 @@ __global__ __launch_bounds__(NT, NT == 256 ? (CHAIN ? 4 : 3) : 2) void conv_igem
             }
         }
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + off));
-        if constexpr (CHAIN != 0) *reinterpret_cast<u32x4 *>(E + p_local * EP_STRIDE + cc * 16) = v;  // the FINAL value (residual, ReLU)
     }
-    if constexpr (CHAIN != 0) {
-        static_assert(CHAIN == 0 || (CT == 256 && PT == 64 && WC == 2 && WP == 2 && MF == 0), "chain tile");
-        constexpr int C2 = CHAIN * 64, E2S = C2 * 2 + 16;
-        // second GEMM  y2[px, c2] = sum_k E[px, k] * w2[c2, k]:  A fragments (w2 rows, K contiguous: the packed layout of a 1x1
-        // conv on 256 channels) straight from global / L2 -- requested before the barrier so their latency overlaps it --,
-        // B fragments (pixels) from the epilogue image.  Wave (wc, wp): c2 fragments wc*CHAIN + f, pixel fragment wp.
-        f32x16 acc2[CHAIN];
-        float4 bv2[CHAIN][4];
-#pragma unroll
-        for (int f = 0; f < CHAIN; ++f) {
-            if (CHAIN > 1) break;  // two fragments per wave: requested after the MFMAs instead (register budget of four waves / SIMD)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bv2[f][g] = *reinterpret_cast<const float4 *>(a.b2 + (wc * CHAIN + f) * 32 + 8 * g + 4 * lh);
-        }
-#pragma unroll
-        for (int f = 0; f < CHAIN; ++f) {
-            const uint16_t *wrow = a.w2 + (size_t)((wc * CHAIN + f) * 32 + lr) * CT + lh * 8;
-            bf16x8 fa2[CT / 16];
-#pragma unroll
-            for (int kk = 0; kk < CT / 16; ++kk) fa2[kk] = *reinterpret_cast<const bf16x8 *>(wrow + kk * 16);
-            if (f == 0) __syncthreads();  // every final value of the tile is in the image
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc2[f][e] = 0.f;
-            const char *Bp = E + (wp * 32 + lr) * EP_STRIDE + lh * 16;
-#pragma unroll
-            for (int kk = 0; kk < CT / 16; ++kk) {
-                const bf16x8 fb2 = *reinterpret_cast<const bf16x8 *>(Bp + kk * 32);
-                acc2[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2[kk], fb2, acc2[f], 0, 0, 0);
-            }
-        }
-        if constexpr (CHAIN > 1) {
-#pragma unroll
-            for (int f = 0; f < CHAIN; ++f)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) bv2[f][g] = *reinterpret_cast<const float4 *>(a.b2 + (wc * CHAIN + f) * 32 + 8 * g + 4 * lh);
-        }
-        __syncthreads();  // all waves are done reading the image: reuse it for the [pixel][c2] transpose
-#pragma unroll
-        for (int f = 0; f < CHAIN; ++f) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c_local = (wc * CHAIN + f) * 32 + 8 * g + 4 * lh;
-                const f32x2 s01 = (f32x2){acc2[f][4 * g + 0], acc2[f][4 * g + 1]} + (f32x2){bv2[f][g].x, bv2[f][g].y};
-                const f32x2 s23 = (f32x2){acc2[f][4 * g + 2], acc2[f][4 * g + 3]} + (f32x2){bv2[f][g].z, bv2[f][g].w};
-                uint2 pk;
-                pk.x = pk_bf16(s01.x, s01.y);
-                pk.y = pk_bf16(s23.x, s23.y);
-                if (a.relu2) { pk.x = pk_relu_bf16(pk.x); pk.y = pk_relu_bf16(pk.y); }
-                *reinterpret_cast<uint2 *>(E + (wp * 32 + lr) * E2S + c_local * 2) = pk;
-            }
-        }
-        __syncthreads();
-        constexpr int CPP2 = C2 / 8;
-#pragma unroll
-        for (int it = 0; it < PT * CPP2 / NT; ++it) {
-            const int e = tid + it * NT;
-            const int p_local = e / CPP2, cc = e % CPP2;
-            const int m = pix0 + p_local;
-            if (m >= a.M) continue;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(E + p_local * E2S + cc * 16);
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y2 + (size_t)m * C2 + cc * 8));
-        }
-    }
-    if (a.stamp && blockIdx.x == gridDim.x / 2) {
+    if (kDiag && a.stamp && a.dbg && blockIdx.x == gridDim.x / 2) {
         stp[5] = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t_done = __builtin_readcyclecounter();
         if (tid == 0) {
-            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(a.y);
-            for (int i = 0; i < 6; ++i) dbg[i] = stp[i];
-            dbg[6] = t_done;
+            for (int i = 0; i < 6; ++i) a.dbg[i] = stp[i];
+            a.dbg[6] = t_done;
         }
     }
 }
@@ -626,24 +567,6 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
-
-// 1x1 conv (256 output channels, plain addressing) + the chained 1x1 conv of the next layer (a.c2 = 64 / 128 channels)
-static int launch_conv_chain(ConvArgs &a, hipStream_t s) {
-    constexpr int CT = 256, PT = 64;
-    g_last_kernel = MD_CONV_KERNEL_OTHER;
-    a.n_ctiles = 1;
-    a.n_ptiles = (a.M + PT - 1) / PT;
-    a.single_buf = 1;
-    constexpr int tile_bytes = (CT + PT) * ROWB, ep_bytes = PT * (CT * 2 + 16);
-    a.bias_lds_off = ep_bytes;            // the bias copy sits behind the epilogue image, inside the (dead) staging buffer:
-    const int lds = tile_bytes > ep_bytes + CT * 4 ? tile_bytes : ep_bytes + CT * 4;   // 40 KiB -> four workgroups per CU
-    a.pt_per_xcd = (a.n_ptiles + 7) / 8;
-    const long long blocks = (long long)a.pt_per_xcd * 8;
-    if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
-    auto k = a.c2 == 64 ? conv_igemm_kernel<256, 2, 2, 4, 1, 2, 0, 0, 1> : conv_igemm_kernel<256, 2, 2, 4, 1, 2, 0, 0, 2>;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, a);
-    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with HALO REUSE.
@@ -1238,12 +1161,12 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         if (ABL == 2 && v[0] != 0x12345u) continue;
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + out_offset(m, c)));
     }
-    if (ABL == 4 && blockIdx.x == (gridDim.x / 2 & ~7u)) {  // diagnostic build only: a mid-grid workgroup's stamps overwrite the first output pixels
+    if (ABL == 4 && a.dbg && blockIdx.x == (gridDim.x / 2 & ~7u)) {  // MD_DIAG build only: a mid-grid workgroup's stamps -> the stamp buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long clk_end = __builtin_readcyclecounter();
         __syncthreads();
         if (lane == 0) {
-            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(a.y) + wave * 16;
+            unsigned long long *dbg = a.dbg + wave * 16;
             for (int i = 0; i < 11; ++i) dbg[i] = keep[i];
             dbg[11] = clk1 - clk0; dbg[12] = rt1 - rt0;
             dbg[13] = clk0 - clk_start; dbg[14] = clk_end - clk1;  // prologue / epilogue cycles
@@ -1299,14 +1222,16 @@ extern "C" long long md_conv2d_set_chunk_limit(long long bytes) {
 
 extern "C" int md_conv2d_cout_tile(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 
-struct HeadArgs {
+struct HeadArgs {   // the fused RPN head: y2 has 16 channels, y is not written
     const uint16_t *w2;
     const float *b2;
     uint16_t *y2;
-    int chain = 0;   // 0: the fused RPN head (y2 has 16 channels, y is not written); 1: a chained 1x1 conv (y AND y2 written)
-    int c2 = 16;     // channels of y2
-    int relu2 = 0;
 };
+#ifdef MD_DIAG
+static unsigned long long *g_stamp_buf = nullptr;
+// device buffer (>= 8 * 16 * 8 bytes) that receives the cycle stamps of the variant 19 / 25 launches
+extern "C" int md_diag_set_stamp_buffer(void *p) { g_stamp_buf = (unsigned long long *)p; return MD_OK; }
+#endif
 #define MD_ERR_UNSUPPORTED_INTERNAL 100  // conv2d_entry with a head on a layer the fused kernel does not take
 
 static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
@@ -1340,7 +1265,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
                 void *p2[5] = {(char *)params[0] + n0 * x_img, params[1], params[2],
                                params[3] ? (void *)((char *)params[3] + n0 * r_img) : nullptr, (char *)params[4] + n0 * y_img};
                 HeadArgs h2;
-                if (head) { h2 = *head; h2.y2 += n0 * shapes[4][1] * shapes[4][2] * head->c2; }
+                if (head) { h2 = *head; h2.y2 += n0 * shapes[4][1] * shapes[4][2] * 16; }
                 const int rc = conv2d_entry(nparam, p2, ndims, sh2, dtypes, stream, extra, head ? &h2 : nullptr);
                 if (rc != MD_OK) return rc;
             }
@@ -1372,7 +1297,14 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     // one LDS staging buffer by default: measured r01 (tools/conv_ab.py), 4 resident workgroups per CU with a serial
     // DMA -> MFMA loop beat 2 double-buffered ones on every benchmark layer (+8...43 %); variant 2 keeps the double buffer
     a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 25;
-    a.stamp = at->variant == 25;
+    a.stamp = 0; a.dbg = nullptr;
+    if ((at->variant >= 17 && at->variant <= 19) || at->variant == 25) {
+        // timing ablations / stamp builds: wrong results by construction, so not part of the product library
+        if (!kDiag) return MD_ERR_ARG;
+#ifdef MD_DIAG
+        a.stamp = at->variant == 25; a.dbg = g_stamp_buf;
+#endif
+    }
     if (at->variant == 25) variant_override = 2;
     if (at->variant == 20) variant_override = 2;
     if (a.res_up && a.adv) return MD_ERR_ARG;
@@ -1419,8 +1351,8 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     hipStream_t s = (hipStream_t)stream;
     // variant: 0 = auto (cost model below); 1 = register-staged 128x128; 2 = LDS-DMA 128x128 with two staging buffers;
     // 5 = 128x128 on v_mfma 16x16x32; 11 = 128-cout halo kernel; 15 / 22 = ping-pong kernel (32x32x16 / 16x16x32 MFMA);
-    // 17-19 = ping-pong timing ablations / stamps (wrong results); 20 = LDS-DMA 128x128 with one staging buffer;
-    // 25 = 20 + stamps; 27 = 64-cout halo kernel
+    // 20 = LDS-DMA 128x128 with one staging buffer; 27 = 64-cout halo kernel; 17-19 / 25 = timing ablations / stamps, MD_DIAG
+    // builds only (the product library answers MD_ERR_ARG)
     int variant = variant_override >= 0 ? variant_override : at->variant;
     const long long x_bytes = (long long)a.N * a.H * a.W * a.Xs * 2 - (at->x_cin > 0 ? at->x_c_off * 2 : 0), w_bytes = (long long)cout_pad * a.Kpad * 2;
     const bool dma_ok = x_bytes < 0x7fff0000LL && w_bytes < 0x7fff0000LL;  // 32-bit DMA offsets, out-of-range marker 2^31
@@ -1446,13 +1378,6 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     const double sb_part = 2.5 + 1.5 * sb_last, sb_lone = 0.0726 * (double)(a.Kpad / BK);
     const double t_sb = (double)(sb_blocks / 1024) * 4.0 + (sb_blocks % 1024 ? (sb_part > sb_lone ? sb_part : sb_lone) : 0.0);
     const bool pp_ok = fast && dma_ok && a.Cout % 256 == 0 && a.Kpad >= 1024 && pp_blocks >= 128 && t_pp <= t_sb;
-    if (head && head->chain) {
-        if (!(fast && dma_ok && a.Cout == 256 && cout_pad == 256 && !a.adv && !a.res_up && !a.Rs && a.relu != 2 && a.pointwise &&
-              a.Kpad == a.Kreal && (head->c2 == 64 || head->c2 == 128) && variant == 0))
-            return MD_ERR_UNSUPPORTED_INTERNAL;
-        a.w2 = head->w2; a.b2 = head->b2; a.y2 = head->y2; a.c2 = head->c2; a.relu2 = head->relu2;
-        return launch_conv_chain(a, s);
-    }
     if (head) {
         if (!(fast && dma_ok && a.Cout == 256 && !a.adv && !a.res && a.relu == 1 && pp_blocks >= 64)) return MD_ERR_UNSUPPORTED_INTERNAL;
         a.w2 = head->w2; a.b2 = head->b2; a.y2 = head->y2;
@@ -1488,8 +1413,10 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     if (variant == 11) variant = 2;
     if (variant == 15 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0>(a, s);  // 256x256 ping-pong, 8 waves
     if (variant == 22 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0, 1>(a, s);  // same, 16x16x32 MFMA
+#ifdef MD_DIAG
     if (variant >= 17 && variant <= 19 && fast && dma_ok && a.Cout % 256 == 0)                       // timing ablations
         return variant == 17 ? launch_conv_pingpong<1>(a, s) : (variant == 18 ? launch_conv_pingpong<2>(a, s) : launch_conv_pingpong<4>(a, s));
+#endif
     if (ctile != 128) {
         if (variant == 1) return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 0>(a, s) : launch_conv<256, 1, 4, 1, 2, 0>(a, s);
         if (fast) return ctile == 64 ? launch_conv<256, 1, 4, 2, 2, 2>(a, s) : launch_conv<256, 1, 4, 1, 2, 2>(a, s);
@@ -1547,37 +1474,5 @@ extern "C" int md_conv2d_head(MD_AOT_ARGS) {
     int64_t *sh1[5] = {sy, sw2, sb2, snull, shapes[5]};
     const char *dt1[5] = {"bfloat16", "bfloat16", "float32", nullptr, "bfloat16"};
     void *p1[5] = {tmp.ptr, params[3], params[4], nullptr, params[5]};
-    return conv2d_entry(5, p1, nd1, sh1, dt1, stream, &a1, nullptr);
-}
-
-// 1x1 conv to 256 channels (+ residual, + ReLU: the bottleneck's expand conv) followed by the NEXT layer's 1x1 conv on those 256
-// channels (64 or 128 outputs, + bias, optional ReLU), both results written: one launch where the chained kernel applies
-// (conv_igemm_kernel<.., CHAIN>: the second conv is computed from the output tile in LDS), otherwise two md_conv2d launches.
-extern "C" int md_conv2d_chain(MD_AOT_ARGS) {
-    // in: x[N,H,W,Cin], w[256,Kpad], bias[256], residual[N,H,W,256] | NULL ; out: y[N,H,W,256] ; in: w2[C2pad,256], bias2[C2pad] ;
-    // out: y2[N,H,W,C2]
-    if (nparam != 8) return MD_ERR_NPARAM;
-    if (!params || !extra || !ndims || !shapes || !params[1] || !params[2] || !params[5] || !params[6]) return MD_ERR_ARG;
-    if (!dtype_is(dtypes, 5, "bfloat16") || !dtype_is(dtypes, 6, "float32") || !dtype_is(dtypes, 7, "bfloat16")) return MD_ERR_ARG;
-    if (ndims[0] != 4 || ndims[4] != 4 || ndims[5] != 2 || ndims[7] != 4) return MD_ERR_ARG;
-    const md_conv2d_attrs *at = (const md_conv2d_attrs *)extra;
-    const int64_t C2 = shapes[7][3];
-    if (shapes[4][3] != 256 || shapes[5][1] != 256 || C2 < 8 || C2 % 8 || shapes[5][0] < C2 || numel(ndims, shapes, 6) < C2 ||
-        shapes[7][0] != shapes[4][0] || shapes[7][1] != shapes[4][1] || shapes[7][2] != shapes[4][2] || at->adv || at->res_upsample)
-        return MD_ERR_ARG;
-    if (numel(ndims, shapes, 7) == 0) return MD_OK;
-    if (!params[7]) return MD_ERR_ARG;
-    HeadArgs head = {(const uint16_t *)params[5], (const float *)params[6], (uint16_t *)params[7], 1, (int)C2, at->chain_relu != 0};
-    int rc = conv2d_entry(5, params, ndims, shapes, dtypes, stream, extra, &head);
-    if (rc != MD_ERR_UNSUPPORTED_INTERNAL) return rc;
-    rc = conv2d_entry(5, params, ndims, shapes, dtypes, stream, extra, nullptr);
-    if (rc != MD_OK) return rc;
-    md_conv2d_attrs a1 = {};
-    a1.kh = a1.kw = 1; a1.stride = 1; a1.pad = 0; a1.relu = at->chain_relu != 0; a1.variant = 0;
-    int64_t snull[1] = {0};
-    int nd1[5] = {4, 2, ndims[6], 0, 4};
-    int64_t *sh1[5] = {shapes[4], shapes[5], shapes[6], snull, shapes[7]};
-    const char *dt1[5] = {"bfloat16", "bfloat16", "float32", nullptr, "bfloat16"};
-    void *p1[5] = {params[4], params[5], params[6], nullptr, params[7]};
     return conv2d_entry(5, p1, nd1, sh1, dt1, stream, &a1, nullptr);
 }

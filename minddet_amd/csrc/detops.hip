@@ -513,7 +513,20 @@ struct RoiArgs {
     int L, C, P, sampling, aligned;
     int k_min, canonical_level; float canonical_scale;
     int N;  // batch images
+    // level map by exact comparisons: RoI goes to level k_min + #{j in 1..L-1 : area >= lvl_thr[j-1]}, where
+    // lvl_thr[j-1] = fp32((canonical_scale * (2^(k_min+j-canonical_level) - 1e-6))^2) (computed in double on the host): the
+    // same predicate as floor(k0 + log2(sqrt(wh)/224 + 1e-6)) >= k_min + j (Lin et al. 2017 eq. 1) without a transcendental,
+    // so the integer level is bit-exact against any restatement that compares the fp32 area with the same table
+    float lvl_thr[5];
 };
+__device__ __forceinline__ int roi_fpn_level(const RoiArgs &a, const float *roi) {
+    const float w = roi[3] - roi[1], h = roi[4] - roi[2];
+    const float area = fmaxf(__fmul_rn(w, h), 0.f);
+    int lvl = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) lvl += (j < a.L - 1 && area >= a.lvl_thr[j]) ? 1 : 0;
+    return lvl;
+}
 __device__ __forceinline__ float rbf2f(unsigned v16) { return __uint_as_float(v16 << 16); }
 __device__ __forceinline__ unsigned rf2bf(float f) {
     unsigned u = __float_as_uint(f);
@@ -541,14 +554,7 @@ __global__ void roi_align_kernel(RoiArgs a, const float *__restrict__ rois, int 
         const int r = (int)(t / a.P);
         const float *roi = rois + (size_t)r * 5;
         const int b = (int)roi[0];
-        // level map: floor(k0 + log2(sqrt(wh)/224 + 1e-6)) clamped (Lin et al. 2017 eq. 1)
-        int lvl = 0;
-        if (a.L > 1) {
-            const float w = roi[3] - roi[1], h = roi[4] - roi[2];
-            const float s = sqrtf(fmaxf(w * h, 0.f));
-            const float lf = floorf((float)a.canonical_level + log2f(s / a.canonical_scale + 1e-6f));
-            lvl = (int)fminf(fmaxf(lf, (float)a.k_min), (float)(a.k_min + a.L - 1)) - a.k_min;
-        }
+        const int lvl = roi_fpn_level(a, roi);
         if (out_level && c8 == 0 && ph == 0 && pw == 0) out_level[r] = lvl + a.k_min;
         const RoiLevel L = a.lv[lvl];
         const float off = a.aligned ? 0.5f : 0.f;
@@ -612,13 +618,7 @@ __global__ __launch_bounds__(256) void roi_align_c32_kernel(RoiArgs a, const flo
         const int r = (int)(t / a.P);
         const float *roi = rois + (size_t)r * 5;
         const int b = (int)roi[0];
-        int lvl = 0;
-        if (a.L > 1) {
-            const float w = roi[3] - roi[1], h = roi[4] - roi[2];
-            const float s = sqrtf(fmaxf(w * h, 0.f));
-            const float lf = floorf((float)a.canonical_level + log2f(s / a.canonical_scale + 1e-6f));
-            lvl = (int)fminf(fmaxf(lf, (float)a.k_min), (float)(a.k_min + a.L - 1)) - a.k_min;
-        }
+        const int lvl = roi_fpn_level(a, roi);
         if (out_level && c32 == 0 && ph == 0 && pw == 0) out_level[r] = lvl + a.k_min;
         const RoiLevel L = a.lv[lvl];
         const float off = a.aligned ? 0.5f : 0.f;
@@ -1147,6 +1147,10 @@ extern "C" int md_roi_align(MD_AOT_ARGS) {
     a.L = L; a.P = at->pooled; a.sampling = at->sampling_ratio; a.aligned = at->aligned;
     a.k_min = at->k_min; a.canonical_level = at->canonical_level; a.canonical_scale = at->canonical_scale;
     if (a.P < 1 || a.sampling < 1) return MD_ERR_ARG;
+    for (int j = 0; j < 5; ++j) {
+        const double edge = (double)at->canonical_scale * (ldexp(1.0, at->k_min + j + 1 - at->canonical_level) - 1e-6);
+        a.lvl_thr[j] = (float)(edge * edge);
+    }
     a.C = 0; a.N = 0;
     for (int l = 0; l < L; ++l) {
         if (!dtype_is(dtypes, 1 + l, "bfloat16") || ndims[1 + l] != 4) return MD_ERR_ARG;

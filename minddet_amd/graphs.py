@@ -17,9 +17,6 @@ from . import det_ops, nn_ops
 from .registry import BACKBONES, DETECTORS, HEADS, NECKS, ROI_HEAD, build_backbone, build_head, build_neck, build_roi_head
 
 
-# ResNet: expand conv chained into the next block's reduce conv (md_conv2d_chain).  OFF by default: measured r01 on the R50 stage-2
-# layers at batch 60 the chained launch takes 1257 us against 770 + 454 us for the two separate launches
-CHAIN_BLOCKS = os.environ.get("MD_CHAIN_BLOCKS", "0") == "1"
 # per-level proposal selection (slice, top-k, decode) on a side HIP stream behind the level's conv, joined before the NMS: +0.4 % on
 # the benchmark (same-box 1 856 -> 1 863 images/s); 0 = everything on one stream (A/B)
 RPN_OVERLAP = os.environ.get("MD_RPN_OVERLAP", "1") == "1"
@@ -117,14 +114,9 @@ class Bottleneck:
     def modules(self):
         return [self.conv1, self.conv2, self.conv3] + ([self.downsample] if self.downsample else [])
 
-    def __call__(self, x, reduced=None, chain=None):
-        """reduced: conv1(x) if the previous block already produced it; chain: the NEXT block's conv1 -- then conv3 (+ residual
-        + ReLU) and that conv run as one md_conv2d_chain launch and (out, chain(out)) is returned."""
+    def __call__(self, x):
         residual = self.downsample(x) if self.downsample is not None else x
-        out = self.conv2(self.conv1(x) if reduced is None else reduced)
-        if chain is None:
-            return self.conv3(out, residual=residual)
-        return nn_ops.conv2d_chain(out, self.conv3.packed, chain.packed, residual=residual)
+        return self.conv3(self.conv2(self.conv1(x)), residual=residual)
 
 
 @BACKBONES.register_module
@@ -181,19 +173,10 @@ class ResNet:
             x = self.conv1(x)
             x = nn_ops.maxpool2d(x, 3, 2, 1, zero_pad=True)
         outs = []
-        blocks = [(si, b) for si, st in enumerate(self.stages) for b in st]
-        reduced = None
-        for i, (si, b) in enumerate(blocks):
-            nxt = blocks[i + 1][1] if i + 1 < len(blocks) else None
-            # a 256-channel block output feeds the next block's 1x1 reduce conv: chain the two (md_conv2d_chain)
-            if (CHAIN_BLOCKS and isinstance(b, Bottleneck) and nxt is not None and b.conv3.cout == 256 and nxt.conv1.cout in (64, 128)
-                    and nxt.conv1.k == 1 and nxt.conv1.stride == 1 and b.conv3.act != "silu" and nxt.conv1.act != "silu"):
-                x, nxt_reduced = b(x, reduced=reduced, chain=nxt.conv1)
-            else:
-                x, nxt_reduced = (b(x, reduced=reduced) if isinstance(b, Bottleneck) else b(x)), None
-            reduced = nxt_reduced
-            if nxt is None or blocks[i + 1][0] != si:
-                outs.append(x)
+        for st in self.stages:
+            for b in st:
+                x = b(x)
+            outs.append(x)
         return tuple(outs)
 
 

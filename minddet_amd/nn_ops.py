@@ -20,7 +20,7 @@ class _ConvAttrs(ctypes.Structure):
                 ("out_stride", ctypes.c_int32), ("out_off_y", ctypes.c_int32), ("out_off_x", ctypes.c_int32),
                 ("c_off", ctypes.c_int32), ("cout", ctypes.c_int32), ("res_upsample", ctypes.c_int32), ("korder", ctypes.c_int32),
                 ("x_c_off", ctypes.c_int32), ("x_cin", ctypes.c_int32), ("res_slice", ctypes.c_int32), ("res_c_off", ctypes.c_int32),
-                ("chain_relu", ctypes.c_int32)]
+                ("reserved0", ctypes.c_int32)]
 
 
 def cout_tile(cout):
@@ -136,22 +136,6 @@ def conv2d_head(x, pc, pc2, variant=None):
     attrs.korder = getattr(pc, "korder", 0)
     _lib.call("md_conv2d_head", [x, pc.w, pc.bias, pc2.w, pc2.bias, y2], extra=attrs)
     return y2
-
-
-def conv2d_chain(x, pc, pc2, residual=None):
-    """y = act(conv1x1(x) [+ residual]) with 256 channels and y2 = act2(conv1x1(y)) in one md_conv2d_chain call (the bottleneck's
-    expand conv chained into the next block's reduce conv); the library falls back to two launches where the chained kernel does
-    not apply.  -> (y, y2)"""
-    n, h, w, c = x.shape
-    if c != pc.cin or pc.cout != 256 or pc2.cin != 256 or (pc.kh, pc.stride, pc.pad, pc2.kh, pc2.stride, pc2.pad) != (1, 1, 0, 1, 1, 0) or \
-            pc.relu == 2 or pc2.relu == 2:
-        raise _lib.MindDetHipError("conv2d_chain: needs a 1x1 conv to 256 channels followed by a 1x1 conv on those channels (ReLU or no activation)")
-    y = torch.empty((n, h, w, 256), dtype=torch.bfloat16, device=x.device)
-    y2 = torch.empty((n, h, w, pc2.cout), dtype=torch.bfloat16, device=x.device)
-    attrs = _ConvAttrs(1, 1, 1, 0, int(pc.relu), int(CONV_VARIANT))
-    attrs.chain_relu = int(pc2.relu)
-    _lib.call("md_conv2d_chain", [x, pc.w, pc.bias, residual, y, pc2.w, pc2.bias, y2], extra=attrs)
-    return y, y2
 
 
 class PackedConvT:

@@ -60,3 +60,49 @@ def gather_masks(masks, group=None, force=False):
     dist.all_gather_into_tensor(out, m16, group=group)
     return out
 
+
+
+class GatherHandle:
+    """An all_gather in flight.  torch.distributed runs an async collective on the backend's own stream behind an event of the
+    issuing stream (RCCL: ProcessGroupNCCL's internal stream), so the caller's compute stream goes on with the next batch;
+    result() makes the CURRENT stream wait for the collective (no host block on RCCL) and unpacks.  The handle keeps the send /
+    receive buffers alive until then."""
+
+    def __init__(self, works, det_out, mask_out, local):
+        self._works, self._det_out, self._mask_out, self._local = works, det_out, mask_out, local
+        self._done = None
+
+    def result(self):
+        if self._done is None:
+            for w in self._works:
+                w.wait()
+            if self._det_out is None:
+                self._done = self._local
+            else:
+                d, c = unpack_gathered(self._det_out)
+                self._done = (d, c) if self._mask_out is None else (d, c, self._mask_out)
+            self._works = ()
+        return self._done
+
+
+def gather_detections_async(dets, count, masks=None, group=None, force=False):
+    """gather_detections (+ gather_masks when `masks` is given) issued with async_op=True: returns a GatherHandle at once.  SURVEY
+    8e: "issue it on a side stream overlapped with the next batch's backbone" -- the caller enqueues the next step's forward pass
+    and calls handle.result() afterwards."""
+    local = (dets, count) if masks is None else (dets, count, masks.to(torch.float16).contiguous())
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
+        return GatherHandle((), None, None, local)
+    world = dist.get_world_size(group)
+    buf = pack_for_gather(dets, count)
+    out = torch.empty((world * buf.shape[0],) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
+    works = [dist.all_gather_into_tensor(out, buf, group=group, async_op=True)]
+    m_out = None
+    keep = [buf]
+    if masks is not None:
+        m16 = local[2]
+        m_out = torch.empty((world * m16.shape[0],) + tuple(m16.shape[1:]), dtype=m16.dtype, device=m16.device)
+        works.append(dist.all_gather_into_tensor(m_out, m16, group=group, async_op=True))
+        keep.append(m16)
+    h = GatherHandle(works, out, m_out, local)
+    h._keep = keep
+    return h

@@ -453,12 +453,27 @@ def roi_align(feat, rois, out_size, spatial_scale, sampling_ratio=2, aligned=Tru
 
 
 def fpn_level(rois, k_min=2, k_max=5, canonical=224.0, canonical_level=4):
-    """FPN RoI -> level map (Lin et al. 2017, eq. 1): floor(4 + log2(sqrt(wh)/224)) clamped.
-    parity unpinned (SURVEY a12 dagger)."""
+    """FPN RoI -> level map (Lin et al. 2017, eq. 1): floor(4 + log2(sqrt(wh)/224 + 1e-6)) clamped to [k_min, k_max],
+    evaluated WITHOUT a transcendental: level >= k  <=>  sqrt(wh)/224 + 1e-6 >= 2^(k-4)  <=>  wh >= (224*(2^(k-4) - 1e-6))^2.
+    The fp32 area is compared with the fp32-rounded thresholds (computed in double), so the integer level is an exact function of
+    the fp32 box corners.  parity unpinned (SURVEY a12 dagger: the reference has no FPN)."""
+    rois = np.asarray(rois, np.float32)
     w = rois[:, 2] - rois[:, 0]
     h = rois[:, 3] - rois[:, 1]
-    s = np.sqrt(np.maximum(w * h, np.float32(0)))
-    lvl = np.floor(canonical_level + np.log2(s / np.float32(canonical) + np.float32(1e-6)))
+    area = np.maximum((w * h).astype(np.float32), np.float32(0))
+    lvl = np.full(rois.shape[0], k_min, np.int32)
+    for k in range(k_min + 1, k_max + 1):
+        edge = np.float64(np.float32(canonical)) * (np.ldexp(1.0, k - canonical_level) - 1e-6)
+        lvl += (area >= np.float32(edge * edge)).astype(np.int32)
+    return lvl
+
+
+def fpn_level_log2(rois, k_min=2, k_max=5, canonical=224.0, canonical_level=4):
+    """The textbook transcendental form (double precision), kept to show the threshold form above is the same map away
+    from the level edges."""
+    rois = np.asarray(rois, np.float64)
+    s = np.sqrt(np.maximum((rois[:, 2] - rois[:, 0]) * (rois[:, 3] - rois[:, 1]), 0.0))
+    lvl = np.floor(canonical_level + np.log2(s / canonical + 1e-6))
     return np.clip(lvl, k_min, k_max).astype(np.int32)
 
 

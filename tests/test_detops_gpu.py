@@ -164,14 +164,26 @@ def test_roi_align_vs_oracle():
     rois = np.stack([rng.integers(0, 2, R), cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).astype(np.float32)
     rois[0, 1:] = [-20, -20, 30, 30]      # partly outside
     rois[1, 1:] = [330, 190, 400, 260]    # mostly outside
+    # RoIs exactly ON the level edges (sqrt(wh) = 112, 224, 448: the upper level), one ulp below them, at the clamps
+    # (tiny -> P2, huge -> P5, degenerate -> P2)
+    edge = []
+    for sz in (112.0, 224.0, 448.0):
+        edge.append([0, 0.0, 0.0, sz, sz])                                              # on the edge: upper level
+        edge.append([1, 0.0, 0.0, sz, np.nextafter(np.float32(sz), np.float32(0))])    # 1 ulp below: still upper (the 1e-6 of the formula)
+        edge.append([0, 0.0, 0.0, sz, sz * (1 - 1e-5)])                                 # clearly below: lower level
+        edge.append([0, 0.0, 0.0, sz * 2, sz / 2])
+    edge += [[0, 5.0, 5.0, 6.0, 6.0], [1, -500.0, -500.0, 2000.0, 2000.0], [0, 50.0, 50.0, 50.0, 80.0], [1, 60.0, 60.0, 40.0, 90.0]]
+    rois = np.concatenate([rois, np.asarray(edge, np.float32)], 0)
+    R = rois.shape[0]
     out, lv = det_ops.roi_align([f.to(DEV) for f in fb], T(rois), 7, scales, 2, True, return_levels=True)
     out, lv = out.float().cpu().numpy(), lv.cpu().numpy()
     lv_o = np_ops.fpn_level(rois[:, 1:])
-    agree = lv == lv_o
-    assert agree.mean() > 0.95  # level boundaries can flip on a last-bit log2 difference
+    np.testing.assert_array_equal(lv, lv_o)   # integer work: exact (threshold comparisons on both sides)
+    assert lv_o[60:72].tolist() == [3, 3, 2, 3, 4, 4, 3, 4, 5, 5, 4, 5] and lv_o[72:].tolist() == [2, 5, 2, 2]
+    # the threshold form is the textbook floor(4 + log2(sqrt(wh)/224 + 1e-6)) away from the edges
+    far = np.abs(np.log2(np.sqrt(np.maximum((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]), 1e-9)) / 224) % 1.0 - 0.5) < 0.49
+    np.testing.assert_array_equal(lv_o[far], np_ops.fpn_level_log2(rois[far, 1:]))
     for r in range(R):
-        if not agree[r]:
-            continue
         l = lv[r] - 2
         f = fb[l][int(rois[r, 0])].float().numpy().transpose(2, 0, 1)
         ref = np_ops.roi_align(f, rois[r:r + 1, 1:], 7, scales[l], 2, True)[0].transpose(1, 2, 0)

@@ -108,9 +108,11 @@ def test_roi_stage(tiny):
         if (r % post) >= cnt[r // post]:
             continue
         ref = np_ops.roi_align(feats[lv[r]][int(rois[r, 0])], rois[r:r + 1, 1:], roi.P, 1.0 / roi.strides[lv[r]], 2, True)[0]
-        if np.abs(pooled[r] - ref.transpose(1, 2, 0)).max() <= 1e-2 * (1 + np.abs(ref).max()):
-            checked += 1
-    assert checked >= 0.9 * len([r for r in range(0, rois.shape[0], 7) if (r % post) < cnt[r // post]])
+        # the FPN level is an exact integer map on both sides, so EVERY sampled RoI pools from the oracle's level
+        err = np.abs(pooled[r] - ref.transpose(1, 2, 0)).max()
+        assert err <= 1e-2 * (1 + np.abs(ref).max()), (r, int(lv[r]), float(err))
+        checked += 1
+    assert checked > 0
     # FC stack on the device's pooled features vs fp32 torch (bf16-rounded weights)
     x2 = torch.from_numpy(pooled.reshape(rois.shape[0], -1))
     for mod in (roi.fc1, roi.fc2, roi.fc_out):
@@ -190,9 +192,8 @@ def test_end_to_end_agreement_in_map_units():
     assert r["fp32 oracle"]["AP"] >= 0.70, r
 
 
-def test_chained_bottlenecks_match_unchained_and_oracle():
-    """A 64-wide Bottleneck ResNet (stage 2 has 256 channels): with the expand conv chained into the next block's reduce conv
-    (md_conv2d_chain, graphs.CHAIN_BLOCKS) the features equal the block-by-block path and the torch-CPU oracle."""
+def test_deep_bottleneck_stack_matches_oracle():
+    """A 64-wide Bottleneck ResNet, ~25 bf16-rounded layers deep, against the torch-CPU oracle."""
     from minddet_amd import graphs
 
     bb = graphs.ResNet(depth=50, base_width=64, layers=[3, 2, 1, 1], seed=9).to(DEV)
@@ -200,20 +201,11 @@ def test_chained_bottlenecks_match_unchained_and_oracle():
     x8 = torch.zeros((2, 96, 160, 8))
     x8[..., :3] = torch.randn((2, 96, 160, 3), generator=g)
     xb = x8.to(torch.bfloat16)
-    old = graphs.CHAIN_BLOCKS
-    try:
-        graphs.CHAIN_BLOCKS = True
-        chained = bb(xb.to(DEV))
-        graphs.CHAIN_BLOCKS = False
-        plain = bb(xb.to(DEV))
-    finally:
-        graphs.CHAIN_BLOCKS = old
+    feats = bb(xb.to(DEV))
     ref = nets.resnet_forward(bb, xb[..., :3].float().permute(0, 3, 1, 2).contiguous(), quant=True)
-    for f_c, f_p, f_ref in zip(chained, plain, ref):
+    for f_c, f_ref in zip(feats, ref):
         rms = f_ref.pow(2).mean().sqrt().item()
-        tol = 3e-2 * max(rms, 1e-3) + 3e-3 * f_ref.abs().max().item()
-        assert (f_c.float() - f_p.float()).abs().max().item() <= tol
-        # ~25 bf16-rounded layers deep: the distance to the oracle is judged as an rms (2 %) with a loose cap on single values
+        # the distance to the oracle is judged as an rms (2 %) with a loose cap on single values
         d = f_c.float().cpu().permute(0, 3, 1, 2) - f_ref
         assert d.pow(2).mean().sqrt().item() <= 2e-2 * max(rms, 1e-3)
         assert d.abs().max().item() <= 0.1 * f_ref.abs().max().item()

@@ -2,12 +2,18 @@
 Prints, for the last K tile of workgroup 0, the cycles each wave spent in: reads+DMA issue | waits | barrier A |
 MFMA cluster | barrier B, for both phases.  Usage: python tools/pp_stamps.py [H W Cin Cout k]"""
 import os
+import subprocess
 import sys
 
+os.environ["MD_DIAG_LIB"] = "1"   # the -DMD_DIAG build (make -C minddet_amd/csrc diag); the product library rejects variant 19
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from minddet_amd import nn_ops
+from minddet_amd import _lib, nn_ops
+
+subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc"), "diag", "-j8"])
+stamps = torch.zeros(8 * 16, dtype=torch.int64, device="cuda:0")
+_lib.lib().md_diag_set_stamp_buffer(__import__("ctypes").c_void_p(stamps.data_ptr()))
 
 H, W, Cin, Cout, k = [int(v) for v in sys.argv[1:6]] if len(sys.argv) > 5 else (200, 336, 256, 256, 3)
 g = torch.Generator().manual_seed(0)
@@ -17,7 +23,7 @@ x = torch.randn((32 if H > 1 else 8, H, W, Cin), generator=g).to(torch.bfloat16)
 for _ in range(5):
     y = nn_ops.conv2d(x, pc, variant=19)
 torch.cuda.synchronize()
-raw = y.view(-1)[: 8 * 64].view(torch.int64).cpu().reshape(8, 16)
+raw = stamps.cpu().reshape(8, 16)
 st = raw[:, :11]
 nk = k * k * Cin // 64
 print(f"main loop: {int(raw[0, 11])} cycles = {int(raw[0, 11]) / nk:.0f} per K tile, in-kernel clock "
