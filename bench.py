@@ -575,6 +575,10 @@ def main(argv=None):
                        "global_batch": world * B, "parallelism": f"dp{world} (image sharding + all_gather of detections)",
                        "gmac_per_image": None if gmac is None else round(gmac, 2), "weights": "random init, seed 7"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "from_uint8": from_u8,
+            # images (over every step of this run) whose class-wise NMS saw a FULL top-nms_pre prefix and fewer than max_det
+            # survivors: only those can differ from the NMS over every candidate (DESIGN.md "pre-NMS prefix"); read after timing
+            "nms_prefix": None if not hasattr(model, "prefix_status") else {
+                "nms_pre": getattr(getattr(model, "roi_head", model), "nms_pre", None), "image_slots_flagged": model.prefix_status.flagged()},
             "lib": os.path.relpath(_lib.LIB_PATH, ROOT),
         }
         print(json.dumps(line))

@@ -303,10 +303,27 @@ typedef struct md_anchor3d_attrs {
     double z_offset;      /* anchor_offsets[2] */
     double size[3];       /* one size triple (w,l,h) */
     double rotations[8];
+    int32_t slot_off, slots_total; /* slots_total > 0: this generator fills rows [slot_off, slot_off + R) of the [.., slots_total, 7]
+                                      anchor table of each location -- TargetAssigner.generate_anchors' concat of several generators
+                                      on axis -2 (pointpillars/src/core/target_assigner.py:227-249) written in place; 0 = standalone */
 } md_anchor3d_attrs;
 /* create_anchors_3d_stride (pointpillars/src/core/box_np_ops.py:453-523) for ONE size:
- * out anchors[1,H,W,1,R,7] f32, bit-identical to the numpy result (np.arange float32 fill). */
+ * out anchors[1,H,W,1,R,7] f32 (or [1,H,W,slots_total,7]), bit-identical to the numpy result (np.arange float32 fill). */
 int md_anchors_3d_stride(MD_AOT_ARGS);
+
+typedef struct md_anchor3d_range_attrs {
+    int32_t feat_d, feat_h, feat_w, num_sizes /* <= 4 */, num_rot /* <= 8 */;
+    int32_t linspace_mode;  /* np.linspace arithmetic: 0 = float32 products and sums (numpy >= 2, what the reference's code computes
+                               on a current numpy: pinned by tests/golden/anchors_range_vectors.npz), 1 = float64 rounded once
+                               (numpy 1.21, the reference's requirements pin; restated from numpy's source, parity unpinned) */
+    int32_t slot_off, slots_total; /* as in md_anchor3d_attrs */
+    double range[6];        /* anchor_range x0,y0,z0,x1,y1,z1 */
+    double sizes[4][3];
+    double rotations[8];
+} md_anchor3d_range_attrs;
+/* create_anchors_3d_range (pointpillars/src/core/box_np_ops.py:526-568): out anchors[D,H,W,S,R,7] f32 (or [D,H,W,slots_total,7]),
+ * centres on np.linspace(range_lo, range_hi, n) per axis (the last one exactly range_hi). */
+int md_anchors_3d_range(MD_AOT_ARGS);
 
 typedef struct md_anchor_mask_attrs {
     int32_t grid_x, grid_y;
@@ -413,7 +430,11 @@ int md_rcnn_scores(MD_AOT_ARGS);
 int md_rcnn_decode_selected(MD_AOT_ARGS);
 /* class-wise merge + packing (shape of centernet/src/post_process.py:36-61):
  * in boxes[B,npre,4] f32, scores[B,npre] f32, labels[B,npre] i32, keep_idx[B,npre] i32, num[B] i32 ;
- * out dets[B,max_det,6] f32 (x1,y1,x2,y2,score,label; zero padded), count[B] i32 */
+ * out dets[B,max_det,6] f32 (x1,y1,x2,y2,score,label; zero padded), count[B] i32.
+ * 9-parameter form: in ... num, sel_cnt[B] i32 (candidates the pre-NMS top-k selected) ; out dets, count, status[B] i32
+ * (IN/OUT, caller-cleared): bit 0 is OR-ed in when the NMS saw a FULL prefix (sel_cnt >= npre) and found fewer than
+ * max_det survivors -- the one case in which the top-npre cut can change the result of the untruncated class-wise NMS
+ * (DESIGN.md "pre-NMS prefix"); clear = provably identical to running the NMS on every candidate. */
 int md_pack_detections(MD_AOT_ARGS);
 
 /* ------------------------------------------------------------------------------------------

@@ -2,6 +2,8 @@
 //
 // Reference counterparts (minddet/models/...):
 //   md_anchors_3d_stride   pointpillars/src/core/box_np_ops.py:453-523 (create_anchors_3d_stride)
+//   md_anchors_3d_range    pointpillars/src/core/box_np_ops.py:526-568 (create_anchors_3d_range); both write into the
+//                          concatenated table of several generators (pointpillars/src/core/target_assigner.py:227-249)
 //   md_anchor_mask         pointpillars/src/data/preprocess.py:211-225 +
 //                          pointpillars/src/core/box_np_ops.py:745-776
 //   md_second_box_decode   pointpillars/src/core/box_ops.py:47-85 / box_np_ops.py:40-67
@@ -51,6 +53,7 @@ __global__ void anchors_fpn_kernel(FpnArgs a, float4 *__restrict__ out, size_t t
 // PointPillars anchors, layout [1,H,W,S(=1 size slot per call),R,7]; np.arange float32 fill
 // semantics: v[i] = first + float(i) * delta with delta = f32(second) - f32(first).
 struct Anchor3dArgs {
+    int slot_off, slots;   // rows [slot_off, slot_off + R) of the [.., slots, 7] anchor table of a location (concat of generators)
     int H, W, R;
     float x_first, x_delta, y_first, y_delta, z;
     float size[3];
@@ -62,11 +65,49 @@ __global__ void anchors_3d_stride_kernel(Anchor3dArgs a, float *__restrict__ out
         const int r = (int)(e % a.R);
         const size_t loc = e / a.R;
         const int x = (int)(loc % a.W), y = (int)(loc / a.W);
-        float *o = out + e * 7;
+        float *o = out + (loc * a.slots + a.slot_off + r) * 7;
         o[0] = a.x_first + (float)x * a.x_delta;
         o[1] = a.y_first + (float)y * a.y_delta;
         o[2] = a.z;
         o[3] = a.size[0]; o[4] = a.size[1]; o[5] = a.size[2];
+        o[6] = a.rot[r];
+    }
+}
+
+// create_anchors_3d_range (pointpillars/src/core/box_np_ops.py:526-568): centres = np.linspace(lo, hi, n, dtype=float32) per axis.
+// numpy's linspace: step = f32(f32(hi - lo) / (n - 1)), v[i] = i * step + lo, v[n-1] = hi exactly; the product and sum run
+//   mode 0: in float32 (numpy >= 2: NEP 50 keeps float32 scalars float32 -- what the reference code computes on this image),
+//   mode 1: in float64, rounded once to float32 (numpy 1.21, the reference's pin: result_type(f32, f32, float(num)) = float64).
+struct LinAxis { float lo, hi, step; int n; };
+struct Anchor3dRangeArgs {
+    int D, H, W, S, R, mode, slot_off, slots;
+    LinAxis ax[3];   // x, y, z
+    float size[4][3];
+    float rot[8];
+};
+__device__ __forceinline__ float linspace_at(const LinAxis &ax, int i, int mode) {
+    if (ax.n > 1 && i == ax.n - 1) return ax.hi;
+    if (ax.step == 0.f) {   // numpy's any_step_zero branch: (i / div) * delta + lo
+        const float delta = ax.hi - ax.lo;
+        if (mode == 0) return ((float)i / (float)(ax.n - 1)) * delta + ax.lo;
+        return (float)(((double)i / (double)(ax.n - 1)) * (double)delta + (double)ax.lo);
+    }
+    if (mode == 0) return (float)i * ax.step + ax.lo;
+    return (float)((double)i * (double)ax.step + (double)ax.lo);
+}
+__global__ void anchors_3d_range_kernel(Anchor3dRangeArgs a, float *__restrict__ out) {
+    const size_t total = (size_t)a.D * a.H * a.W * a.S * a.R;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e % a.R);
+        size_t t = e / a.R;
+        const int sz = (int)(t % a.S);
+        const size_t loc = t / a.S;
+        const int x = (int)(loc % a.W), y = (int)((loc / a.W) % a.H), z = (int)(loc / ((size_t)a.W * a.H));
+        float *o = out + (loc * a.slots + a.slot_off + sz * a.R + r) * 7;
+        o[0] = linspace_at(a.ax[0], x, a.mode);
+        o[1] = linspace_at(a.ax[1], y, a.mode);
+        o[2] = linspace_at(a.ax[2], z, a.mode);
+        o[3] = a.size[sz][0]; o[4] = a.size[sz][1]; o[5] = a.size[sz][2];
         o[6] = a.rot[r];
     }
 }
@@ -1020,9 +1061,45 @@ extern "C" int md_anchors_3d_stride(MD_AOT_ARGS) {
     for (int i = 0; i < 3; ++i) a.size[i] = (float)at->size[i];
     for (int i = 0; i < a.R; ++i) a.rot[i] = (float)at->rotations[i];
     const int64_t total = (int64_t)a.H * a.W * a.R;
-    if (numel(ndims, shapes, 0) != total * 7) return MD_ERR_ARG;
+    // standalone (slots_total 0): the table of a location has R rows; inside a concat of generators (target_assigner.py:242)
+    // this generator fills rows [slot_off, slot_off + R) of slots_total
+    a.slots = at->slots_total > 0 ? at->slots_total : a.R;
+    a.slot_off = at->slots_total > 0 ? at->slot_off : 0;
+    if (a.slot_off < 0 || a.slot_off + a.R > a.slots) return MD_ERR_ARG;
+    if (numel(ndims, shapes, 0) != (int64_t)a.H * a.W * a.slots * 7) return MD_ERR_ARG;
     hipLaunchKernelGGL(anchors_3d_stride_kernel, dim3(grid1d((size_t)total)), dim3(256), 0, (hipStream_t)stream, a,
                        (float *)params[0]);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}
+
+extern "C" int md_anchors_3d_range(MD_AOT_ARGS) {
+    if (nparam != 1) return MD_ERR_NPARAM;
+    if (!params || !extra || !dtype_is(dtypes, 0, "float32")) return MD_ERR_ARG;
+    const md_anchor3d_range_attrs *at = (const md_anchor3d_range_attrs *)extra;
+    if (at->feat_d < 1 || at->feat_h < 1 || at->feat_w < 1 || at->num_sizes < 1 || at->num_sizes > 4 || at->num_rot < 1 ||
+        at->num_rot > 8 || (at->linspace_mode != 0 && at->linspace_mode != 1))
+        return MD_ERR_ARG;
+    Anchor3dRangeArgs a;
+    a.D = at->feat_d; a.H = at->feat_h; a.W = at->feat_w; a.S = at->num_sizes; a.R = at->num_rot; a.mode = at->linspace_mode;
+    const int n_ax[3] = {a.W, a.H, a.D};
+    for (int i = 0; i < 3; ++i) {   // anchor_range = np.array(anchor_range, float32); linspace(range[i], range[i + 3], n)
+        LinAxis &ax = a.ax[i];
+        ax.lo = (float)at->range[i]; ax.hi = (float)at->range[i + 3]; ax.n = n_ax[i];
+        const float delta = ax.hi - ax.lo;
+        ax.step = ax.n > 1 ? delta / (float)(ax.n - 1) : 0.f;
+    }
+    for (int k = 0; k < a.S; ++k)
+        for (int i = 0; i < 3; ++i) a.size[k][i] = (float)at->sizes[k][i];
+    for (int i = 0; i < a.R; ++i) a.rot[i] = (float)at->rotations[i];
+    const int per = a.S * a.R;
+    a.slots = at->slots_total > 0 ? at->slots_total : per;
+    a.slot_off = at->slots_total > 0 ? at->slot_off : 0;
+    if (a.slot_off < 0 || a.slot_off + per > a.slots) return MD_ERR_ARG;
+    const int64_t locs = (int64_t)a.D * a.H * a.W;
+    if (numel(ndims, shapes, 0) != locs * a.slots * 7) return MD_ERR_ARG;
+    if (!params[0]) return MD_ERR_ARG;
+    hipLaunchKernelGGL(anchors_3d_range_kernel, dim3(grid1d((size_t)locs * per)), dim3(256), 0, (hipStream_t)stream, a, (float *)params[0]);
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }

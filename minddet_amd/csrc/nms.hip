@@ -539,6 +539,16 @@ static int check_boxes7(int nparam, int want, void **params, int *ndims, int64_t
     return MD_OK;
 }
 
+// outputs of the keep-list NMS ops: keep[>= n] and num[>= 1] (the kernels zero keep[0..n) and write num[0] whatever the
+// caller's out_shape lambdas said), no NULL operand when there is work.  Shapes a caller does not describe are not checked.
+static int check_keep_outputs(void **params, int *ndims, int64_t **shapes, int64_t n) {
+    const int64_t keep_n = numel(ndims, shapes, 2), num_n = numel(ndims, shapes, 3);
+    if ((keep_n >= 0 && keep_n < n) || (num_n >= 0 && num_n < 1)) return MD_ERR_ARG;
+    if (!params[3]) return MD_ERR_ARG;
+    if (n > 0 && (!params[0] || !params[1] || !params[2])) return MD_ERR_ARG;
+    return MD_OK;
+}
+
 template <int MODE, typename KeepT>
 static int rot_nms_impl(MD_AOT_ARGS, const char *keep_dtype) {
     int64_t n;
@@ -546,6 +556,8 @@ static int rot_nms_impl(MD_AOT_ARGS, const char *keep_dtype) {
     if (rc) return rc;
     if (!dtype_is(dtypes, 1, "float32") || !dtype_is(dtypes, 2, keep_dtype) || !dtype_is(dtypes, 3, "int32"))
         return MD_ERR_ARG;
+    rc = check_keep_outputs(params, ndims, shapes, n);
+    if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     KeepT *keep = (KeepT *)params[2];
     int *num = (int *)params[3];
@@ -582,6 +594,8 @@ extern "C" int NmsNormalGpu(MD_AOT_ARGS) {
     if (rc) return rc;
     if (!dtype_is(dtypes, 1, "float32") || !dtype_is(dtypes, 2, "int64") || !dtype_is(dtypes, 3, "int32"))
         return MD_ERR_ARG;
+    rc = check_keep_outputs(params, ndims, shapes, n);
+    if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) return hipMemsetAsync(params[3], 0, sizeof(int), s) == hipSuccess ? MD_OK : MD_ERR_HIP;
     const int cb = (int)((n + TILE - 1) / TILE);

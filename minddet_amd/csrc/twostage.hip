@@ -162,7 +162,7 @@ __global__ void rcnn_decode_selected_kernel(const uint16_t *__restrict__ cls_reg
 __global__ void pack_dets_kernel(const float *__restrict__ boxes, const float *__restrict__ scores,
                                  const int *__restrict__ labels, const int *__restrict__ keep_idx,
                                  const int *__restrict__ num, int B, int npre, int max_det, float *__restrict__ dets,
-                                 int *__restrict__ count) {
+                                 int *__restrict__ count, const int *__restrict__ sel_cnt, int *__restrict__ status) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= B * max_det) return;
     const int b = e / max_det, j = e % max_det;
@@ -177,7 +177,14 @@ __global__ void pack_dets_kernel(const float *__restrict__ boxes, const float *_
     } else {
         d[0] = d[1] = d[2] = d[3] = d[4] = d[5] = 0.f;
     }
-    if (j == 0) count[b] = n;
+    if (j == 0) {
+        count[b] = n;
+        // the greedy class-wise NMS ran on the top-npre candidates only.  Its first max_det survivors ARE the first max_det
+        // survivors of the untruncated list (a candidate is suppressed by higher-scored ones only) unless the prefix was full
+        // and ran out before the quota: then candidates beyond it may belong to the result.  Bit 0 is OR-ed in (the caller
+        // owns / clears the word), so a flag raised in any step stays visible without a host synchronisation per step.
+        if (status && sel_cnt && num[b] < max_det && sel_cnt[b] >= npre) status[b] |= 1;
+    }
 }
 
 static void fill_decode(DecodeP &p, const md_delta2bbox_attrs &a) {
@@ -291,20 +298,29 @@ extern "C" int md_rcnn_decode_selected(MD_AOT_ARGS) {
 }
 
 extern "C" int md_pack_detections(MD_AOT_ARGS) {
-    // in: boxes[B,npre,4] f32, scores[B,npre] f32, labels[B,npre] i32, keep_idx[B,npre] i32, num[B] i32
-    // out: dets[B,max_det,6] f32, count[B] i32
-    if (nparam != 7) return MD_ERR_NPARAM;
-    if (!params || !ndims || ndims[1] != 2 || ndims[5] != 3) return MD_ERR_ARG;
+    // in: boxes[B,npre,4] f32, scores[B,npre] f32, labels[B,npre] i32, keep_idx[B,npre] i32, num[B] i32 [, sel_cnt[B] i32]
+    // out: dets[B,max_det,6] f32, count[B] i32 [, status[B] i32 (in/out: bit 0 OR-ed in)]
+    if (nparam != 7 && nparam != 9) return MD_ERR_NPARAM;
+    const int o = nparam == 9 ? 6 : 5;   // index of dets
+    if (!params || !ndims || ndims[1] != 2 || ndims[o] != 3) return MD_ERR_ARG;
     if (!dtype_is(dtypes, 0, "float32") || !dtype_is(dtypes, 1, "float32") || !dtype_is(dtypes, 2, "int32") ||
-        !dtype_is(dtypes, 3, "int32") || !dtype_is(dtypes, 4, "int32") || !dtype_is(dtypes, 5, "float32") ||
-        !dtype_is(dtypes, 6, "int32"))
+        !dtype_is(dtypes, 3, "int32") || !dtype_is(dtypes, 4, "int32") || !dtype_is(dtypes, o, "float32") ||
+        !dtype_is(dtypes, o + 1, "int32"))
         return MD_ERR_ARG;
-    const int B = (int)shapes[1][0], npre = (int)shapes[1][1], max_det = (int)shapes[5][1];
-    if (shapes[5][0] != B || shapes[5][2] != 6) return MD_ERR_ARG;
+    const int B = (int)shapes[1][0], npre = (int)shapes[1][1], max_det = (int)shapes[o][1];
+    if (shapes[o][0] != B || shapes[o][2] != 6) return MD_ERR_ARG;
+    const int *sel_cnt = nullptr;
+    int *status = nullptr;
+    if (nparam == 9) {
+        if (!dtype_is(dtypes, 5, "int32") || !dtype_is(dtypes, 8, "int32") || numel(ndims, shapes, 5) != B || numel(ndims, shapes, 8) != B ||
+            (B > 0 && (!params[5] || !params[8])))
+            return MD_ERR_ARG;
+        sel_cnt = (const int *)params[5]; status = (int *)params[8];
+    }
     if (B * max_det == 0) return MD_OK;
     hipLaunchKernelGGL(pack_dets_kernel, dim3((B * max_det + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        (const float *)params[0], (const float *)params[1], (const int *)params[2], (const int *)params[3],
-                       (const int *)params[4], B, npre, max_det, (float *)params[5], (int *)params[6]);
+                       (const int *)params[4], B, npre, max_det, (float *)params[o], (int *)params[o + 1], sel_cnt, status);
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }

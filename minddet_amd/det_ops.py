@@ -224,6 +224,13 @@ class _FpnAnchorAttrs(ctypes.Structure):
 class _Anchor3dAttrs(ctypes.Structure):
     _fields_ = [("feat_h", ctypes.c_int32), ("feat_w", ctypes.c_int32), ("num_rot", ctypes.c_int32),
                 ("range", ctypes.c_double * 6), ("z_offset", ctypes.c_double), ("size", ctypes.c_double * 3),
+                ("rotations", ctypes.c_double * 8), ("slot_off", ctypes.c_int32), ("slots_total", ctypes.c_int32)]
+
+
+class _Anchor3dRangeAttrs(ctypes.Structure):
+    _fields_ = [("feat_d", ctypes.c_int32), ("feat_h", ctypes.c_int32), ("feat_w", ctypes.c_int32), ("num_sizes", ctypes.c_int32),
+                ("num_rot", ctypes.c_int32), ("linspace_mode", ctypes.c_int32), ("slot_off", ctypes.c_int32),
+                ("slots_total", ctypes.c_int32), ("range", ctypes.c_double * 6), ("sizes", (ctypes.c_double * 3) * 4),
                 ("rotations", ctypes.c_double * 8)]
 
 
@@ -271,10 +278,10 @@ def fpn_anchors(feat_sizes, strides=(4, 8, 16, 32, 64), scale=8.0, ratios=(0.5, 
 
 def create_anchors_3d_stride(feature_size, sizes=(1.6, 3.9, 1.56), anchor_strides=(0.4, 0.4, 0.0),
                              anchor_offsets=(0.2, -39.8, -1.78), rotations=(0, math.pi / 2),
-                             anchor_range=(0.0, -39.68, -3.0, 69.12, 39.68, 1.0), dtype=torch.float32, device="cuda"):
+                             anchor_range=(0.0, -39.68, -3.0, 69.12, 39.68, 1.0), dtype=torch.float32, device="cuda", out=None, slot_off=0):
     """pointpillars/src/core/box_np_ops.py:453-523 on device: returns [1,H,W,1,R,7] fp32.
     (anchor_strides / x,y offsets are unused by the reference too: it derives the stride from
-    anchor_range, :476-477.)"""
+    anchor_range, :476-477.)  out [1,H,W,slots,7] + slot_off: write rows [slot_off, slot_off + R) of a concatenated table."""
     d, h, w = feature_size
     assert d == 1 and len(rotations) == 2, "the reference hard-codes one z slice and two rotations (:492)"
     at = _Anchor3dAttrs()
@@ -287,9 +294,74 @@ def create_anchors_3d_stride(feature_size, sizes=(1.6, 3.9, 1.56), anchor_stride
         at.size[i] = flat[i]
     for i, r in enumerate(rotations):
         at.rotations[i] = float(r)
-    out = torch.empty((1, h, w, 1, len(rotations), 7), dtype=torch.float32, device=device)
+    if out is None:
+        out = torch.empty((1, h, w, 1, len(rotations), 7), dtype=torch.float32, device=device)
+    else:
+        at.slot_off, at.slots_total = int(slot_off), int(out.shape[-2])
     _lib.call("md_anchors_3d_stride", [out], extra=at)
     return out
+
+
+def create_anchors_3d_range(feature_size, anchor_range, sizes=(1.6, 3.9, 1.56), rotations=(0, math.pi / 2), device="cuda",
+                            linspace_mode=0, out=None, slot_off=0):
+    """pointpillars/src/core/box_np_ops.py:526-568 on device: [D,H,W,S,R,7] fp32, centres on np.linspace(lo, hi, n) per axis.
+    linspace_mode: md_anchor3d_range_attrs (0 = the float32 arithmetic of numpy >= 2, 1 = numpy 1.21's float64)."""
+    d, h, w = [int(v) for v in feature_size]
+    flat = [float(v) for row in (sizes if isinstance(sizes[0], (list, tuple)) else [sizes]) for v in row]
+    ns = len(flat) // 3
+    at = _Anchor3dRangeAttrs()
+    at.feat_d, at.feat_h, at.feat_w, at.num_sizes, at.num_rot, at.linspace_mode = d, h, w, ns, len(rotations), int(linspace_mode)
+    for i in range(6):
+        at.range[i] = float(anchor_range[i])
+    for k in range(ns):
+        for i in range(3):
+            at.sizes[k][i] = flat[3 * k + i]
+    for i, r in enumerate(rotations):
+        at.rotations[i] = float(r)
+    if out is None:
+        out = torch.empty((d, h, w, ns, len(rotations), 7), dtype=torch.float32, device=device)
+    else:
+        at.slot_off, at.slots_total = int(slot_off), int(out.shape[-2])
+    _lib.call("md_anchors_3d_range", [out], extra=at)
+    return out
+
+
+class AnchorGeneratorStride:
+    """pointpillars/src/core/anchor_generator.py:6-63 (same constructor arguments and properties); generate() runs on the device."""
+
+    def __init__(self, sizes=(1.6, 3.9, 1.56), anchor_strides=(0.4, 0.4, 1.0), anchor_offsets=(0.2, -39.8, -1.78),
+                 rotations=(0, math.pi / 2), class_id=None, match_threshold=-1, unmatch_threshold=-1,
+                 anchor_range=(0.0, -39.68, -3.0, 69.12, 39.68, 1.0)):
+        self._sizes, self._anchor_strides, self._anchor_offsets, self._rotations = sizes, anchor_strides, anchor_offsets, rotations
+        self.class_id, self.match_threshold, self.unmatch_threshold = class_id, match_threshold, unmatch_threshold
+        self.anchor_range = anchor_range
+
+    @property
+    def num_anchors_per_localization(self):
+        flat = self._sizes if isinstance(self._sizes[0], (list, tuple)) else [self._sizes]
+        return len(self._rotations) * len(flat)
+
+    def generate(self, feature_map_size, device="cuda", out=None, slot_off=0):
+        return create_anchors_3d_stride(feature_map_size, self._sizes, self._anchor_strides, self._anchor_offsets, self._rotations,
+                                        self.anchor_range, device=device, out=out, slot_off=slot_off)
+
+
+def generate_anchors(anchor_generators, feature_map_size, device="cuda"):
+    """TargetAssigner.generate_anchors (pointpillars/src/core/target_assigner.py:227-249): every generator's anchors reshaped to
+    [*shape[:3], -1, 7] and concatenated on axis -2, with the per-anchor matched / unmatched thresholds of its generator.  Each
+    generator writes its rows of the concatenated table in place (no concat copy).  The threshold vectors are ordered as the
+    reference builds them: generator after generator (np.concatenate of np.full blocks), NOT in the anchor table's order."""
+    d, h, w = [int(v) for v in feature_map_size]
+    per = [g.num_anchors_per_localization for g in anchor_generators]
+    out = torch.empty((d, h, w, sum(per), 7), dtype=torch.float32, device=device)
+    off = 0
+    for g, n in zip(anchor_generators, per):
+        g.generate(feature_map_size, device=device, out=out, slot_off=off)
+        off += n
+    locs = d * h * w
+    matched = torch.cat([torch.full((locs * n,), float(g.match_threshold), dtype=torch.float32) for g, n in zip(anchor_generators, per)])
+    unmatched = torch.cat([torch.full((locs * n,), float(g.unmatch_threshold), dtype=torch.float32) for g, n in zip(anchor_generators, per)])
+    return {"anchors": out, "matched_thresholds": matched.to(device), "unmatched_thresholds": unmatched.to(device)}
 
 
 def anchors_mask(coors, grid_size_xy, anchors_bv, voxel_size, pc_range, area_threshold):
@@ -477,12 +549,40 @@ def rcnn_decode_selected(cls_reg, rois, sel_idx, sel_cnt, num_classes, reg_offse
     return boxes, labels
 
 
-def pack_detections(boxes, scores, labels, keep_idx, num, max_det):
+def pack_detections(boxes, scores, labels, keep_idx, num, max_det, sel_cnt=None, status=None):
+    """-> dets [B,max_det,6], count [B].  With sel_cnt (the pre-NMS top-k's counts) and status ([B] int32, caller-cleared, in/out)
+    bit 0 of status[b] is OR-ed in when the top-npre prefix was full AND gave fewer than max_det survivors: only then can the cut
+    differ from the NMS over every candidate (see PrefixStatus)."""
     B = scores.shape[0]
     dets = torch.empty((B, max_det, 6), dtype=torch.float32, device=boxes.device)
     count = torch.empty((B,), dtype=torch.int32, device=boxes.device)
-    _lib.call("md_pack_detections", [boxes, scores, labels, keep_idx, num, dets, count])
+    if status is None:
+        _lib.call("md_pack_detections", [boxes, scores, labels, keep_idx, num, dets, count])
+    else:
+        _lib.call("md_pack_detections", [boxes, scores, labels, keep_idx, num, sel_cnt, dets, count, status])
     return dets, count
+
+
+class PrefixStatus:
+    """Per-image sticky flags of the pre-NMS prefix cut (md_pack_detections, 9-parameter form), kept on the device: the hot path
+    never synchronises for them; `flagged()` reads them (one host sync) when the caller wants to know, `clear()` resets."""
+
+    def __init__(self):
+        self._t = {}
+
+    def tensor(self, batch, device):
+        key = (int(batch), str(device))
+        if key not in self._t:
+            self._t[key] = torch.zeros((batch,), dtype=torch.int32, device=device)
+        return self._t[key]
+
+    def flagged(self):
+        """image slots (of any batch size seen) whose result MAY differ from the untruncated class-wise NMS."""
+        return int(sum(int((t & 1).sum().item()) for t in self._t.values()))
+
+    def clear(self):
+        for t in self._t.values():
+            t.zero_()
 
 
 # ----------------------------------------------------------------------------- CenterPoint head post-processing

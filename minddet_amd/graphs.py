@@ -276,30 +276,38 @@ class RPNHead:
         if RPN_OVERLAP and self._side is None:
             self._side = torch.cuda.Stream(dev)
         keep_alive = []
-        for l, f in enumerate(feats):
-            if RPN_FUSED_HEAD and self.conv.cout == 256 and self.out.packed.cout == 16 and self.conv.relu:
-                head = nn_ops.conv2d_head(f, self.conv.packed, self.out.packed)   # [B,H,W,16], one launch per level
-            else:
-                head = self.out(self.conv(f))
-            heads.append(head)
-
-            def select(l=l, f=f, head=head):
-                logits = nn_ops.slice_cast(head, 0, A)              # [B,H,W,A] fp32
-                _, idx, cnt = det_ops.topk_segmented(logits, st["seg"][l], k, out_cnt=counts[l],
-                                                     max_segment=f.shape[1] * f.shape[2] * A)
-                det_ops.rpn_decode(head, st["anchors"][l], idx, cnt, A, img_hw, out_boxes=boxes[l], out_scores=scores[l])
-                keep_alive.append((logits, idx, cnt))
-
-            if RPN_OVERLAP:
-                ev = torch.cuda.Event()
-                ev.record(main)
-                with torch.cuda.stream(self._side):
-                    self._side.wait_event(ev)
-                    select()
-            else:
-                select()
         if RPN_OVERLAP:
-            main.wait_stream(self._side)
+            # written on the side stream, allocated on the main one: the caching allocator must not hand their memory to a
+            # main-stream allocation while side-stream work may still touch it, whatever happens to the Python references
+            for t in (boxes, scores, counts):
+                t.record_stream(self._side)
+        try:
+            for l, f in enumerate(feats):
+                if RPN_FUSED_HEAD and self.conv.cout == 256 and self.out.packed.cout == 16 and self.conv.relu:
+                    head = nn_ops.conv2d_head(f, self.conv.packed, self.out.packed)   # [B,H,W,16], one launch per level
+                else:
+                    head = self.out(self.conv(f))
+                heads.append(head)
+
+                def select(l=l, f=f, head=head):
+                    logits = nn_ops.slice_cast(head, 0, A)              # [B,H,W,A] fp32
+                    _, idx, cnt = det_ops.topk_segmented(logits, st["seg"][l], k, out_cnt=counts[l],
+                                                         max_segment=f.shape[1] * f.shape[2] * A)
+                    det_ops.rpn_decode(head, st["anchors"][l], idx, cnt, A, img_hw, out_boxes=boxes[l], out_scores=scores[l])
+                    keep_alive.append((logits, idx, cnt))
+
+                if RPN_OVERLAP:
+                    head.record_stream(self._side)
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    with torch.cuda.stream(self._side):
+                        self._side.wait_event(ev)
+                        select()
+                else:
+                    select()
+        finally:
+            if RPN_OVERLAP:
+                main.wait_stream(self._side)   # always joined, also when a level's selection raised
         keep, _, _ = det_ops.nms_aligned(boxes.view(L * B, k, 4), self.nms_thr, mode=det_ops.NMS_MODE_STRICT,
                                          count=counts.view(-1))
         mboxes, mscores = det_ops.rpn_merge(boxes, scores, keep.view(L, B, k))
@@ -336,6 +344,10 @@ class StandardRoIHead:
         self.strides, self.sampling = tuple(featmap_strides), sampling_ratio
         self.score_thr, self.nms_thr, self.max_per_img, self.nms_pre = score_thr, nms_thr, max_per_img, nms_pre
         self._cache = {}
+        # nms_pre: the class-wise NMS runs on the top-nms_pre (roi, class) candidates of an image instead of on all of them (the
+        # public definition: every candidate above score_thr).  The cut is result-identical whenever the prefix yields max_per_img
+        # survivors or was not full; the one other case raises a sticky per-image flag on the device (DESIGN.md "pre-NMS prefix")
+        self.prefix_status = det_ops.PrefixStatus()
 
     def modules(self):
         return [self.fc1, self.fc2, self.fc_out]
@@ -363,7 +375,8 @@ class StandardRoIHead:
         boxes, labels = det_ops.rcnn_decode_selected(cls_reg, rois, si, sc, self.nc, self.reg_offset, img_hw)
         keep, kidx, num = det_ops.nms_aligned(boxes, self.nms_thr, mode=det_ops.NMS_MODE_STRICT, count=sc, group=labels,
                                               max_output=self.max_per_img)
-        dets, count = det_ops.pack_detections(boxes, sv, labels, kidx, num, self.max_per_img)
+        dets, count = det_ops.pack_detections(boxes, sv, labels, kidx, num, self.max_per_img, sel_cnt=sc,
+                                              status=self.prefix_status.tensor(B, dev))
         return dets, count, dict(pooled=pooled, cls_reg=cls_reg, cand=cand, sel_scores=sv, sel_idx=si, sel_cnt=sc,
                                  boxes=boxes, labels=labels, keep=keep)
 
@@ -389,6 +402,11 @@ class FasterRCNN:
 
     def conv_modules(self):
         return self.backbone.modules() + self.neck.modules() + self.rpn_head.modules() + self.roi_head.modules()
+
+    @property
+    def prefix_status(self):
+        """sticky device flags of the second stage's top-nms_pre cut (det_ops.PrefixStatus)"""
+        return self.roi_head.prefix_status
 
     def extract_feat(self, images):
         return self.neck(self.backbone(images))
@@ -790,6 +808,7 @@ class YOLOv5:
         self.detect = [ConvModule(init, c, no, 1, bn=False, relu=False, bias=True, std=0.02) for c in (c256, c512, c1024)]
         self.strides = (8, 16, 32)
         self.conf_thres, self.iou_thres, self.max_det, self.nms_pre = conf_thres, iou_thres, max_det, nms_pre
+        self.prefix_status = det_ops.PrefixStatus()   # sticky flags of the top-nms_pre cut (see StandardRoIHead)
         self.c = (c256, c512)
         self._seg = {}
 
@@ -854,7 +873,7 @@ class YOLOv5:
         sl = torch.gather(labels, 1, si.long())
         keep, kidx, num = det_ops.nms_aligned(sb, self.iou_thres, mode=det_ops.NMS_MODE_STRICT, count=sc, group=sl,
                                               max_output=self.max_det)
-        dets, count = det_ops.pack_detections(sb, sv, sl, kidx, num, self.max_det)
+        dets, count = det_ops.pack_detections(sb, sv, sl, kidx, num, self.max_det, sel_cnt=sc, status=self.prefix_status.tensor(B, dev))
         if return_aux:
             return dets, count, dict(heads=heads, boxes=boxes, scores=scores, labels=labels, sel_idx=si, sel_cnt=sc,
                                      sel_boxes=sb, sel_labels=sl, keep=keep)
@@ -938,6 +957,7 @@ class YOLOv8:
                              ConvModule(init, c3, num_classes, 1, bn=False, relu=False, bias=True, std=0.05)])
         self.strides = (8, 16, 32)
         self.conf_thres, self.iou_thres, self.max_det, self.nms_pre = conf_thres, iou_thres, max_det, nms_pre
+        self.prefix_status = det_ops.PrefixStatus()   # sticky flags of the top-nms_pre cut (see StandardRoIHead)
         self._seg = {}
         self._stem2 = {}
 
@@ -1012,7 +1032,7 @@ class YOLOv8:
         sb = det_ops.gather_rows(boxes, si, sc)
         sl = torch.gather(labels, 1, si.long())
         keep, kidx, num = det_ops.nms_aligned(sb, self.iou_thres, mode=det_ops.NMS_MODE_STRICT, count=sc, group=sl, max_output=self.max_det)
-        dets, count = det_ops.pack_detections(sb, sv, sl, kidx, num, self.max_det)
+        dets, count = det_ops.pack_detections(sb, sv, sl, kidx, num, self.max_det, sel_cnt=sc, status=self.prefix_status.tensor(B, dev))
         if return_aux:
             return dets, count, dict(heads=heads, boxes=boxes, scores=scores, labels=labels, sel_idx=si, sel_cnt=sc, sel_boxes=sb,
                                      sel_labels=sl, keep=keep)

@@ -201,28 +201,61 @@ def create_anchors_3d_stride(feature_size, sizes=(1.6, 3.9, 1.56), anchor_stride
     return np.transpose(anchors, [2, 1, 0, 3, 4, 5])
 
 
+def linspace_f32(lo, hi, n, mode=0):
+    """np.linspace(lo, hi, n, dtype=float32) for float32 scalars lo / hi, restated from numpy's source so that BOTH arithmetic
+    regimes are available whatever numpy runs the test: mode 0 = float32 products and sums (numpy >= 2, NEP 50), mode 1 = float64
+    rounded once (numpy 1.21, the reference's pin: result_type(f32, f32, float(num)) is float64 there).  step is float32 in both:
+    f32(f32(hi - lo) / (n - 1)); the last element is hi exactly."""
+    lo, hi = np.float32(lo), np.float32(hi)
+    i = np.arange(n)
+    if n == 1:
+        return np.array([lo], np.float32)
+    delta = np.float32(hi - lo)
+    step = np.float32(delta / np.float32(n - 1))
+    if mode == 0:
+        f = i.astype(np.float32)
+        y = (f / np.float32(n - 1)) * delta if step == 0 else f * step
+        y = (y.astype(np.float32) + lo).astype(np.float32)
+    else:
+        f = i.astype(np.float64)
+        y = (f / np.float64(n - 1)) * np.float64(delta) if step == 0 else f * np.float64(step)
+        y = (y + np.float64(lo)).astype(np.float32)
+    y[-1] = hi
+    return y
+
+
 def create_anchors_3d_range(feature_size, anchor_range, sizes=(1.6, 3.9, 1.56),
-                            rotations=(0, np.pi / 2), dtype=np.float32):
-    """PP/src/core/box_np_ops.py:526-568 (np.meshgrid result listed for numpy >= 2)."""
+                            rotations=(0, np.pi / 2), dtype=np.float32, linspace_mode=0):
+    """PP/src/core/box_np_ops.py:526-568: [D,H,W,S,R,7] = (x, y, z centre on np.linspace per axis, size triple, rotation)."""
     anchor_range = np.array(anchor_range, dtype)
-    z_centers = np.linspace(anchor_range[2], anchor_range[5], feature_size[0], dtype=dtype)
-    y_centers = np.linspace(anchor_range[1], anchor_range[4], feature_size[1], dtype=dtype)
-    x_centers = np.linspace(anchor_range[0], anchor_range[3], feature_size[2], dtype=dtype)
+    z_centers = linspace_f32(anchor_range[2], anchor_range[5], feature_size[0], linspace_mode)
+    y_centers = linspace_f32(anchor_range[1], anchor_range[4], feature_size[1], linspace_mode)
+    x_centers = linspace_f32(anchor_range[0], anchor_range[3], feature_size[2], linspace_mode)
     sizes = np.reshape(np.array(sizes, dtype=dtype), [-1, 3])
     rotations = np.array(rotations, dtype=dtype)
-    rets = list(np.meshgrid(x_centers, y_centers, z_centers, rotations, indexing="ij"))
-    tile_shape = [1] * 5
-    tile_shape[-2] = int(sizes.shape[0])
-    for i in range(len(rets)):
-        rets[i] = np.tile(rets[i][..., np.newaxis, :], tile_shape)
-        rets[i] = rets[i][..., np.newaxis]
-    sizes = np.reshape(sizes, [1, 1, 1, -1, 1, 3])
-    tile_size_shape = list(rets[0].shape)
-    tile_size_shape[3] = 1
-    sizes = np.tile(sizes, tile_size_shape)
-    rets.insert(3, sizes)
-    ret = np.concatenate(rets, axis=-1)
-    return np.transpose(ret, [2, 1, 0, 3, 4, 5])
+    D, H, W, S, R = len(z_centers), len(y_centers), len(x_centers), sizes.shape[0], len(rotations)
+    out = np.zeros((D, H, W, S, R, 7), dtype)
+    out[..., 0] = x_centers[None, None, :, None, None]
+    out[..., 1] = y_centers[None, :, None, None, None]
+    out[..., 2] = z_centers[:, None, None, None, None]
+    out[..., 3:6] = sizes[None, None, None, :, None, :]
+    out[..., 6] = rotations[None, None, None, None, :]
+    return out
+
+
+def generate_anchors(generators, feature_map_size):
+    """TargetAssigner.generate_anchors (PP/src/core/target_assigner.py:227-249): generators = list of dicts of
+    create_anchors_3d_stride keyword arguments + match_threshold / unmatch_threshold."""
+    tabs, match, unmatch = [], [], []
+    for g in generators:
+        kw = {k: v for k, v in g.items() if k not in ("match_threshold", "unmatch_threshold")}
+        a = create_anchors_3d_stride(feature_map_size, **kw)
+        a = a.reshape([*a.shape[:3], -1, 7])
+        tabs.append(a)
+        n = int(np.prod(a.shape[:-1]))
+        match.append(np.full([n], g["match_threshold"], a.dtype))
+        unmatch.append(np.full([n], g["unmatch_threshold"], a.dtype))
+    return {"anchors": np.concatenate(tabs, axis=-2), "matched_thresholds": np.concatenate(match), "unmatched_thresholds": np.concatenate(unmatch)}
 
 
 def anchors_mask(coors, grid_size_xy, anchors_bv, voxel_size, pc_range, area_threshold):

@@ -36,6 +36,39 @@ def test_anchors_3d_stride_bit_exact(golden):
         np.testing.assert_array_equal(got, np_ops.create_anchors_3d_stride([1, 248, 296], **cfg))
 
 
+def test_anchors_3d_range_and_generator_concat_bit_exact():
+    """md_anchors_3d_range == the reference's create_anchors_3d_range (golden, run on this image's numpy = linspace_mode 0) and
+    == the oracle in both linspace modes; the cyclist + pedestrian generators written in place into ONE table == the reference's
+    TargetAssigner.generate_anchors (values, order and thresholds)."""
+    from minddet_amd import det_ops
+    from test_oracle_golden import PED_CYCLE, RANGE_CASES, anchors_golden
+
+    g = anchors_golden()
+    for tag, kw in RANGE_CASES.items():
+        got = det_ops.create_anchors_3d_range(**kw).cpu().numpy()
+        np.testing.assert_array_equal(got, np_ops.create_anchors_3d_range(**kw))
+        if tag != "c":
+            np.testing.assert_array_equal(got, g[f"range_{tag}"])
+        else:
+            np.testing.assert_array_equal(got.reshape(-1, 7)[::997], g["range_c_sample"])
+        got1 = det_ops.create_anchors_3d_range(**kw, linspace_mode=1).cpu().numpy()
+        np.testing.assert_array_equal(got1, np_ops.create_anchors_3d_range(**kw, linspace_mode=1))
+    gens = [det_ops.AnchorGeneratorStride(**{k: v for k, v in d.items()}) for d in PED_CYCLE]
+    r = det_ops.generate_anchors(gens, [1, 13, 17])
+    np.testing.assert_array_equal(r["anchors"].cpu().numpy(), g["concat_small_anchors"])
+    np.testing.assert_array_equal(r["matched_thresholds"].cpu().numpy(), g["concat_small_matched"])
+    np.testing.assert_array_equal(r["unmatched_thresholds"].cpu().numpy(), g["concat_small_unmatched"])
+    f = det_ops.generate_anchors(gens, [1, 248, 296])
+    flat = f["anchors"].cpu().numpy().reshape(-1, 7)
+    assert list(f["anchors"].shape) == g["concat_full_shape"].tolist()
+    np.testing.assert_array_equal(flat[::1009], g["concat_full_sample"])
+    np.testing.assert_allclose(flat.astype(np.float64).sum(0), g["concat_full_sum64"], rtol=1e-12)
+    np.testing.assert_array_equal(f["matched_thresholds"].cpu().numpy()[::1009], g["concat_full_matched_sample"])
+    with pytest.raises(Exception, match="rc=2"):   # a generator that does not fit its slot range
+        det_ops.create_anchors_3d_stride([1, 13, 17], **{k: v for k, v in PED_CYCLE[0].items() if "threshold" not in k},
+                                         out=r["anchors"], slot_off=3)
+
+
 def test_fpn_anchors_bit_exact_full_size():
     from minddet_amd import det_ops
 

@@ -79,6 +79,21 @@ def test_size_limits_and_bad_arguments_return_codes():
                              torch.zeros((4,), dtype=torch.int32, device=DEV), torch.zeros((1,), dtype=torch.int32, device=DEV)])
     with pytest.raises(_lib.MindDetHipError, match="rc=1"):
         _lib.call("md_iou_aligned", [torch.zeros((4, 4), device=DEV)])
+    # keep-list NMS ops: an output shorter than the box list (or a missing num / operand) is an argument error, not an
+    # out-of-bounds device write; the 65536-box cap is a size error (rc 4)
+    for op, kdt in (("NmsGpu", torch.int64), ("NmsNormalGpu", torch.int64), ("boxes_iou_nms_gpu", torch.int32)):
+        guard = torch.full((8,), -5, dtype=kdt, device=DEV)
+        with pytest.raises(_lib.MindDetHipError, match="rc=2"):
+            _lib.call(op, [torch.rand((8, 7), device=DEV), torch.full((1,), 0.5, device=DEV), guard[:4], torch.zeros((1,), dtype=torch.int32, device=DEV)])
+        with pytest.raises(_lib.MindDetHipError, match="rc=2"):
+            _lib.call(op, [torch.rand((8, 7), device=DEV), torch.full((1,), 0.5, device=DEV), guard, torch.zeros((0,), dtype=torch.int32, device=DEV)])
+        with pytest.raises(_lib.MindDetHipError, match="rc=2"):
+            _lib.call(op, [torch.rand((8, 7), device=DEV), None, guard, torch.zeros((1,), dtype=torch.int32, device=DEV)])
+        torch.cuda.synchronize()
+        assert bool((guard == -5).all())
+        with pytest.raises(_lib.MindDetHipError, match="rc=4"):
+            _lib.call(op, [torch.zeros((65537, 7), device=DEV), torch.full((1,), 0.5, device=DEV), torch.zeros((65537,), dtype=kdt, device=DEV),
+                           torch.zeros((1,), dtype=torch.int32, device=DEV)])
     pc = nn_ops.pack_conv(torch.randn((64, 64, 3, 3)), stride=1, pad=1).to(DEV)
     with pytest.raises(_lib.MindDetHipError, match="rc=2"):  # output shape does not match the conv geometry
         nn_ops.conv2d(torch.zeros((1, 8, 8, 64), dtype=torch.bfloat16, device=DEV), pc,

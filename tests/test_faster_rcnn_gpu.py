@@ -209,3 +209,107 @@ def test_deep_bottleneck_stack_matches_oracle():
         d = f_c.float().cpu().permute(0, 3, 1, 2) - f_ref
         assert d.pow(2).mean().sqrt().item() <= 2e-2 * max(rms, 1e-3)
         assert d.abs().max().item() <= 0.1 * f_ref.abs().max().item()
+
+
+def _second_stage_device(head, cls_reg, rois, roi_cnt, img_hw):
+    from minddet_amd import det_ops
+
+    head.prefix_status.clear()
+    B = roi_cnt.numel()
+    post = rois.shape[0] // B
+    cand = det_ops.rcnn_scores(cls_reg, roi_cnt, head.nc, head.score_thr)
+    seg = torch.arange(0, (B + 1) * post * head.nc, post * head.nc, dtype=torch.int32, device=DEV)
+    sv, si, sc = det_ops.topk_segmented(cand, seg, head.nms_pre, max_segment=post * head.nc)
+    boxes, labels = det_ops.rcnn_decode_selected(cls_reg, rois, si, sc, head.nc, head.reg_offset, img_hw)
+    keep, kidx, num = det_ops.nms_aligned(boxes, head.nms_thr, mode=det_ops.NMS_MODE_STRICT, count=sc, group=labels, max_output=head.max_per_img)
+    dets, count = det_ops.pack_detections(boxes, sv, labels, kidx, num, head.max_per_img, sel_cnt=sc, status=head.prefix_status.tensor(B, DEV))
+    return dets.cpu().numpy(), count.cpu().numpy(), cand.cpu().numpy(), head.prefix_status.tensor(B, DEV).cpu().numpy()
+
+
+def test_pre_nms_prefix_against_the_untruncated_oracle():
+    """The class-wise NMS of the second stage runs on the top-nms_pre candidates.  With MORE candidates above the threshold than
+    nms_pre: (a) when the prefix yields max_per_img survivors the result equals the UNTRUNCATED definition (every candidate above
+    score_thr -> class-wise NMS -> top max_per_img) and no flag is raised; (b) when the full prefix runs out before the quota the
+    result can differ -- and exactly then the sticky device flag of that image is set; (c) a prefix that was not full never flags."""
+    from minddet_amd import graphs
+
+    nc, post, B = 4, 96, 3
+    head = graphs.StandardRoIHead(in_channels=8, fc_channels=8, num_classes=nc, roi_size=2, score_thr=0.05, nms_thr=0.5, max_per_img=10,
+                                  nms_pre=64, featmap_strides=(4,))
+    rng = np.random.default_rng(21)
+    R = B * post
+    Cp = head.reg_offset + 4 * nc
+    cls_reg = np.zeros((R, (Cp + 7) // 8 * 8), np.float32)
+    rois = np.zeros((R, 5), np.float32)
+    rois[:, 0] = np.repeat(np.arange(B), post)
+    # image 0: well separated RoIs (a 12 x 8 grid of 20-px boxes 40 px apart): nothing suppresses anything -> the quota is
+    #          reached inside the prefix although 96 * 2 = 192 candidates exceed nms_pre = 64
+    gx, gy = np.meshgrid(np.arange(12) * 40.0, np.arange(8) * 40.0)
+    rois[:post, 1], rois[:post, 2] = gx.ravel(), gy.ravel()
+    rois[:post, 3], rois[:post, 4] = gx.ravel() + 20, gy.ravel() + 20
+    # image 1: the 70 best-scored RoIs are near-copies of ONE box (class 0): the full prefix collapses to one survivor per class,
+    #          the separated RoIs behind it would fill the quota -> the cut changes the result, the flag must be raised
+    rois[post:2 * post, 1:] = rois[:post, 1:]
+    rois[post:post + 70, 1:] = np.array([100, 100, 160, 160], np.float32) + rng.uniform(-1, 1, (70, 4)).astype(np.float32)
+    # image 2: only 20 valid RoIs (40 candidates < nms_pre): never flagged
+    rois[2 * post:, 1:] = rois[:post, 1:]
+    roi_cnt = np.array([post, post, 20], np.int32)
+    # two classes above the threshold per RoI (distinct scores), background last
+    logits = np.full((R, nc + 1), -4.0, np.float32)
+    logits[:, 0] = 2.0 + rng.permutation(R).astype(np.float32) * 1e-3
+    logits[:, 1] = 1.0 + rng.permutation(R).astype(np.float32) * 1e-3
+    logits[post:post + 70, 0] += 1.0   # image 1: its first 70 RoIs get the highest class-0 scores
+    cls_reg[:, :nc + 1] = logits
+    cr = torch.from_numpy(cls_reg).to(torch.bfloat16)
+    img_hw = (400, 600)
+    d, c, cand, status = _second_stage_device(head, cr.to(DEV), torch.from_numpy(rois).to(DEV), torch.from_numpy(roi_cnt).to(DEV), img_hw)
+    crf = cr.float().numpy()
+    cand = np.where(cand < -1e30, -np.inf, cand)
+    assert (np.isfinite(cand).sum(1) > head.nms_pre).tolist() == [True, True, False]
+    full, full_c, _ = nets.rcnn_finish(cand, crf, rois, nc, head.reg_offset, img_hw, post * nc, head.nms_thr, head.max_per_img, post)   # untruncated
+    cut, cut_c, _ = nets.rcnn_finish(cand, crf, rois, nc, head.reg_offset, img_hw, head.nms_pre, head.nms_thr, head.max_per_img, post)
+    np.testing.assert_array_equal(c, cut_c)
+    np.testing.assert_array_equal(d[..., 4:], cut[..., 4:])
+    np.testing.assert_allclose(d[..., :4], cut[..., :4], rtol=1e-5, atol=2e-3)
+    assert status.tolist() == [0, 1, 0]
+    for b in (0, 2):   # flag clear => identical to the untruncated definition
+        assert c[b] == full_c[b]
+        np.testing.assert_array_equal(d[b, :, 4:], full[b, :, 4:])
+    assert full_c[1] == head.max_per_img and c[1] < full_c[1]    # the flagged image is the one that differs
+    # the flag is sticky until cleared, and a clean batch does not set it
+    assert head.prefix_status.flagged() == 1
+    head.prefix_status.clear()
+    assert head.prefix_status.flagged() == 0
+
+
+def test_benchmark_batch_60_two_stage_forward():
+    """The benchmark's real shape: R50-FPN 800x1344 at batch 60 in the stem layout -- the P2-level tensors are 2.06 GB, so md_conv2d's
+    > 2 GiB image chunking and every launch grid of bench.py's step run here; structure, determinism, chunk-independence."""
+    from minddet.models import Config, build_detector
+    from minddet_amd import nn_ops
+    from minddet_amd.data import synthetic_images
+
+    cfg = Config.fromfile("configs/faster_rcnn/faster_rcnn_r50_fpn.py")
+    m = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(DEV)
+    x = nn_ops.to_stem_layout(synthetic_images(60, 800, 1344, seed=20240317, device=DEV))
+    dets, count = m.forward(x)
+    dets2, count2 = m.forward(x)
+    torch.cuda.synchronize()
+    assert dets.shape == (60, 100, 6) and count.shape == (60,)
+    assert torch.equal(dets, dets2) and torch.equal(count, count2)
+    d, c = dets.cpu().numpy(), count.cpu().numpy()
+    for b in range(60):
+        n = c[b]
+        assert 0 <= n <= 100 and (np.diff(d[b, :n, 4]) <= 0).all() and (d[b, n:] == 0).all()
+        assert (d[b, :n, 0] >= 0).all() and (d[b, :n, 2] <= 1344).all() and (d[b, :n, 3] <= 800).all()
+    # images are independent: the first four images alone give (nearly: the dispatcher may pick other kernels for the smaller
+    # grids, bf16 rounding then differs in the last bit) the same detections as inside the batch of 60
+    d4, c4 = m.forward(x[:4].contiguous())
+    torch.cuda.synchronize()
+    assert (c4.cpu() - count[:4].cpu()).abs().max().item() <= 5
+    for b in range(4):
+        if c[b] > 0 and int(c4[b]) > 0:
+            assert abs(float(d4[b, 0, 4]) - float(dets[b, 0, 4])) <= 2e-2
+    assert c.sum() > 0
+    st = m.prefix_status
+    assert st.flagged() >= 0

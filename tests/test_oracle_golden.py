@@ -1,6 +1,8 @@
 """The CPU oracle against the golden vectors the REFERENCE produced (tests/golden/gen_golden.py).
 
 These pin the oracle; the -m gpu tests then compare the HIP path with the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -96,12 +98,64 @@ def test_anchor_mask(golden):
     assert mask.sum() > 0
 
 
+RANGE_CASES = {
+    "a": dict(feature_size=[1, 31, 27], anchor_range=[0.0, -39.68, -1.78, 69.12, 39.68, -1.78], sizes=[1.6, 3.9, 1.56], rotations=[0, 1.57]),
+    "b": dict(feature_size=[2, 7, 5], anchor_range=[0.1, -3.3, -3.0, 7.7, 3.3, 1.0], sizes=[[0.6, 1.76, 1.73], [0.6, 0.8, 1.73]], rotations=[0, 0.785, 1.57]),
+    "c": dict(feature_size=[1, 248, 216], anchor_range=[0.0, -39.68, -1.0, 69.12, 39.68, -1.0], sizes=[1.6, 3.9, 1.56], rotations=[0, np.pi / 2]),
+    "d": dict(feature_size=[1, 1, 4], anchor_range=[2.0, 5.0, 0.5, 2.0, 6.0, 0.5], sizes=[1.0, 2.0, 3.0], rotations=[0.0]),
+}
+PED_CYCLE = [
+    dict(sizes=[0.6, 1.76, 1.73], anchor_strides=[0.16, 0.16, 0.0], anchor_offsets=[0.08, -19.76, -1.465], rotations=[0, 1.57],
+         anchor_range=[0, -19.84, -2.5, 47.36, 19.84, 0.5], match_threshold=0.5, unmatch_threshold=0.35),
+    dict(sizes=[0.6, 0.8, 1.73], anchor_strides=[0.16, 0.16, 0.0], anchor_offsets=[0.08, -19.76, -1.2], rotations=[0, 1.57],
+         anchor_range=[0, -19.84, -2.5, 47.36, 19.84, 0.5], match_threshold=0.45, unmatch_threshold=0.3),
+]
+
+
+def anchors_golden():
+    return dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "anchors_range_vectors.npz"), allow_pickle=False))
+
+
+def test_anchor_range_equals_the_reference():
+    """create_anchors_3d_range restated (np_ops, linspace_mode 0) == the reference's own function run on this image's numpy
+    (tests/golden/gen_anchors.py), bit for bit; mode 1 (numpy 1.21 arithmetic, parity unpinned) stays within an ulp of the range's scale."""
+    g = anchors_golden()
+    for tag in ("a", "b", "d"):
+        a = np_ops.create_anchors_3d_range(**RANGE_CASES[tag])
+        np.testing.assert_array_equal(a, g[f"range_{tag}"])
+        a1 = np_ops.create_anchors_3d_range(**RANGE_CASES[tag], linspace_mode=1)
+        assert (np.abs(a1.astype(np.float64) - a) <= 2.0 ** -22 * np.maximum(np.abs(a), 64.0)).all()   # an ulp of the range's largest centre
+    c = np_ops.create_anchors_3d_range(**RANGE_CASES["c"])
+    assert list(c.shape) == g["range_c_shape"].tolist()
+    flat = c.reshape(-1, 7)
+    np.testing.assert_array_equal(flat[::997], g["range_c_sample"])
+    np.testing.assert_allclose(flat.astype(np.float64).sum(0), g["range_c_sum64"], rtol=1e-12)
+    # the restated linspace is numpy's own on this image
+    for lo, hi, n in ((0.0, 69.12, 216), (-39.68, 39.68, 248), (0.1, 7.7, 5), (2.0, 2.0, 4), (3.0, 9.0, 1)):
+        np.testing.assert_array_equal(np_ops.linspace_f32(lo, hi, n, 0), np.linspace(np.float32(lo), np.float32(hi), n, dtype=np.float32))
+
+
 def test_anchor_range_known_answer():
     a = np_ops.create_anchors_3d_range([1, 4, 5], [0, -2, -1, 4, 2, -1], sizes=[1, 2, 3], rotations=[0, 1.57])
     assert a.shape == (1, 4, 5, 1, 2, 7)
     np.testing.assert_allclose(a[0, 0, :, 0, 0, 0], np.linspace(0, 4, 5), rtol=1e-6)
     np.testing.assert_allclose(a[0, :, 0, 0, 0, 1], np.linspace(-2, 2, 4), rtol=1e-6)
     np.testing.assert_allclose(a[0, 1, 2, 0, 1], [2, -2 + 4 / 3, -1, 1, 2, 3, 1.57], rtol=1e-6)
+
+
+def test_two_generator_anchor_table_equals_the_reference():
+    """TargetAssigner.generate_anchors over the cyclist + pedestrian stride generators (target_assigner.py:227-249)."""
+    g = anchors_golden()
+    r = np_ops.generate_anchors(PED_CYCLE, [1, 13, 17])
+    np.testing.assert_array_equal(r["anchors"], g["concat_small_anchors"])
+    np.testing.assert_array_equal(r["matched_thresholds"], g["concat_small_matched"])
+    np.testing.assert_array_equal(r["unmatched_thresholds"], g["concat_small_unmatched"])
+    f = np_ops.generate_anchors(PED_CYCLE, [1, 248, 296])
+    assert list(f["anchors"].shape) == g["concat_full_shape"].tolist()
+    flat = f["anchors"].reshape(-1, 7)
+    np.testing.assert_array_equal(flat[::1009], g["concat_full_sample"])
+    np.testing.assert_allclose(flat.astype(np.float64).sum(0), g["concat_full_sum64"], rtol=1e-12)
+    np.testing.assert_array_equal(f["matched_thresholds"][::1009], g["concat_full_matched_sample"])
 
 
 def test_known_answer_shapes_from_reference_comments():

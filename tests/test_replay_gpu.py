@@ -45,3 +45,36 @@ def test_captured_step_equals_eager(which):
             assert torch.equal(tg, te)
     with pytest.raises(ValueError):
         step(_batch(3, (1,) + shape[1:]))
+
+
+def test_rpn_side_stream_overlap_is_bit_identical():
+    """graphs.RPN_OVERLAP (per-level proposal selection on a side stream behind the level's conv): detections equal the single-stream
+    path bit for bit, eager and under CapturedStep, on several batches in a row (a stream hazard would show as a mismatch)."""
+    from minddet.models import Config, build_detector
+    from minddet_amd import graphs
+    from minddet_amd.replay import CapturedStep
+
+    cfg = Config.fromfile("configs/faster_rcnn/faster_rcnn_tiny.py")
+    m = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(DEV)
+    shape = (3,) + tuple(cfg.data.input_hw) + (8,)
+    batches = [_batch(s, shape) for s in (11, 12, 13)]
+    old = graphs.RPN_OVERLAP
+    try:
+        graphs.RPN_OVERLAP = False
+        ref = []
+        for x in batches:
+            d, c = m.forward(x)
+            ref.append((d.clone(), c.clone()))
+        torch.cuda.synchronize()
+        graphs.RPN_OVERLAP = True
+        for _ in range(2):
+            for x, (d0, c0) in zip(batches, ref):
+                d, c = m.forward(x)
+                assert torch.equal(d, d0) and torch.equal(c, c0)
+        step = CapturedStep(lambda x: tuple(m.forward(x)), batches[0])
+        for x, (d0, c0) in zip(batches, ref):
+            d, c = step(x)
+            torch.cuda.synchronize()
+            assert torch.equal(d, d0) and torch.equal(c, c0)
+    finally:
+        graphs.RPN_OVERLAP = old

@@ -63,6 +63,48 @@ def test_yolov5s_end_to_end():
     assert int(count.sum()) > 0
 
 
+def test_yolov5s_full_size_batch32_structure():
+    """BASELINE.json configs[1] in its stated form: YOLOv5s 640x640 bf16, batch 32 on one GPU -- shapes, padding, score order,
+    determinism, select / class-aware NMS / packing bit-exact from the device tensors on sampled images, and the pre-NMS prefix
+    flags (conf_thres lowered so that random-init heads produce candidates)."""
+    from minddet.models import Config, build_detector
+    from minddet_amd.data import synthetic_images
+
+    cfg = Config.fromfile("configs/yolov5/yolov5s.py")
+    cfg.model["conf_thres"] = 0.05
+    m = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(DEV)
+    x = synthetic_images(32, 640, 640, device=DEV)
+    dets, count, aux = m.forward(x, return_aux=True)
+    dets2, count2 = m.forward(x)
+    torch.cuda.synchronize()
+    assert [tuple(h.shape[:3]) for h in aux["heads"]] == [(32, 80, 80), (32, 40, 40), (32, 20, 20)]
+    assert aux["boxes"].shape == (32, 25200, 4) and dets.shape == (32, m.max_det, 6) and count.shape == (32,)
+    assert torch.equal(dets, dets2) and torch.equal(count, count2)              # deterministic
+    d, c = dets.cpu().numpy(), count.cpu().numpy()
+    sd, bd, ld = aux["scores"].cpu().numpy(), aux["boxes"].cpu().numpy(), aux["labels"].cpu().numpy()
+    for b in range(32):
+        n = c[b]
+        assert 0 <= n <= m.max_det and (np.diff(d[b, :n, 4]) <= 0).all() and (d[b, n:] == 0).all()
+        assert (d[b, :n, 2] >= d[b, :n, 0]).all() and (d[b, :n, 3] >= d[b, :n, 1]).all()
+    for b in (0, 13, 31):
+        sc = np.where(sd[b] < -1e30, -np.inf, sd[b])
+        v, i = np_ops.topk_desc_stable(sc, m.nms_pre)
+        k = min(m.nms_pre, int(np.isfinite(sc).sum()))
+        v, i = v[:k], i[:k]
+        assert int(aux["sel_cnt"][b]) == k
+        np.testing.assert_array_equal(aux["sel_idx"].cpu().numpy()[b, :k], i)
+        keep = oracle.nms_aligned(bd[b][i], m.iou_thres, 0.0, 2, groups=ld[b][i]).astype(bool)
+        kidx = np.nonzero(keep)[0][:m.max_det]
+        assert c[b] == len(kidx)
+        np.testing.assert_array_equal(d[b, :len(kidx), :4], bd[b][i][kidx])
+        np.testing.assert_array_equal(d[b, :len(kidx), 4], v[kidx])
+        np.testing.assert_array_equal(d[b, :len(kidx), 5], ld[b][i][kidx])
+    # prefix flags: an image is flagged iff its prefix was full and produced fewer than max_det survivors
+    st = m.prefix_status.tensor(32, DEV).cpu().numpy()
+    selc = aux["sel_cnt"].cpu().numpy()
+    np.testing.assert_array_equal(st & 1, ((selc >= m.nms_pre) & (c < m.max_det)).astype(st.dtype))
+
+
 def test_silu_residual_conv_and_slice_writes():
     from minddet_amd import nn_ops
     import torch.nn.functional as F
