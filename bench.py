@@ -261,7 +261,8 @@ def main(argv=None):
     H, W = cfg.data.input_hw
     B = args.batch
     images = synthetic_images(B, H, W, seed=20240317 + rank, device=dev)
-    if type(model).__name__ in ("FasterRCNN", "MaskRCNN") and nn_ops.stem_layout_ok(H, W) and os.environ.get("MD_STEM_LAYOUT", "1") == "1":
+    if (type(model).__name__ in ("FasterRCNN", "MaskRCNN") and nn_ops.stem_layout_ok(H, W) and os.environ.get("MD_STEM_LAYOUT", "1") == "1"
+            and getattr(model.backbone, "stem", None) is not None):
         # the batch is resident in HBM in the model's input layout before the timed region starts: zero-bordered
         # 4-channel NHWC (md_stem_pool); MD_STEM_LAYOUT=0 keeps the 8-channel layout + two-launch stem for A/B
         images = nn_ops.to_stem_layout(images)
@@ -314,14 +315,14 @@ def main(argv=None):
     if hasattr(nn_ops, "bottleneck"):
         orig_bottleneck = nn_ops.bottleneck
 
-        def timed_bottleneck(x, blk, **kw):
+        def timed_bottleneck(x, blk, residual=None, **kw):
             if _skip():
-                return orig_bottleneck(x, blk, **kw)
+                return orig_bottleneck(x, blk, residual=residual, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            y = orig_bottleneck(x, blk, **kw)
+            y = orig_bottleneck(x, blk, residual=residual, **kw)
             e1.record()
-            fl, byts = blk.flops_bytes(x.shape[0], x.shape[1], x.shape[2])
+            fl, byts = blk.flops_bytes(x.shape[0], x.shape[1], x.shape[2], with_residual_tensor=residual is not None)
             records.append((e0, e1, fl, tuple(x.shape), blk.cout, 3, byts, last_kernel(), None, None))
             return y
 

@@ -181,6 +181,17 @@ int md_conv2d_cout_tile(int cout);
  * extra: md_conv2d_attrs of the FIRST conv (relu must be 1, plain addressing). */
 int md_conv2d_head(MD_AOT_ARGS);
 
+/* A whole ResNet bottleneck block (centernet/src/resnet.py:139-178: conv1 1x1 + bn + relu -> conv2 3x3 + bn + relu -> conv3 1x1 +
+ * bn, + residual, relu) with 64 mid channels, stride 1 and 256 output channels in ONE launch: both 64-channel intermediates stay
+ * in LDS and x is read from HBM once (1024 B of HBM traffic per pixel instead of 2048 B for the three md_conv2d launches, which are
+ * HBM-bound).  Same arithmetic per layer as md_conv2d (bf16 operands, fp32 accumulation in the same K order, bf16-rounded
+ * intermediates), so the result equals the three-launch path bit for bit.
+ * in : x[N,H,W,Cin] bf16 (Cin = 64 or 256), w1[64,Cin] bf16, b12[128] f32 (conv1's 64 biases followed by conv2's),
+ *      w2[64,576] bf16 (K = tap*64 + ci), w3[256,64] bf16, b3[256] f32 (weights as md_conv2d packs them, BN folded),
+ *      residual[N,H,W,256] bf16, or a NULL pointer = x itself (identity block, needs Cin == 256)
+ * out: y[N,H,W,256] bf16.   extra: unused. */
+int md_bottleneck(MD_AOT_ARGS);
+
 /* Which kernel the dispatcher launched for the calling host thread's most recent md_conv2d (0 before any call, or when
  * the call returned without launching).  Diagnostic only: lets bench.py attribute per-launch HIP-event timings. */
 enum {
@@ -190,7 +201,8 @@ enum {
     MD_CONV_KERNEL_IGEMM_SMALL_COUT = 3,/* conv_igemm_kernel 64- / 32-cout tiles */
     MD_CONV_KERNEL_IGEMM_GENERIC_K = 4, /* conv_igemm_kernel generic K walk (the 7x7 stem) */
     MD_CONV_KERNEL_HALO = 5,            /* conv3x3_halo_kernel (3x3 layers with Cout <= 64; variant 11 / 27) */
-    MD_CONV_KERNEL_OTHER = 6            /* A/B variants */
+    MD_CONV_KERNEL_OTHER = 6,           /* A/B variants */
+    MD_CONV_KERNEL_BOTTLENECK = 7       /* bottleneck64_kernel (md_bottleneck) */
 };
 int md_conv2d_last_kernel(void);
 /* md_conv2d runs a batch whose activation tensor exceeds `bytes` (default and maximum: 2 GiB - 64 KiB, the reach of the

@@ -64,4 +64,7 @@ struct Scratch {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// records which conv-family kernel the calling host thread launched last (md_conv2d_last_kernel); defined in conv.hip
+void md_note_conv_kernel(int id);
+
 }  // namespace md

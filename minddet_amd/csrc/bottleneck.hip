@@ -1,0 +1,423 @@
+// bottleneck.hip -- a whole ResNet bottleneck block (stride 1, 64 mid channels) in ONE launch.
+//
+// What it replaces: Bottleneck.construct of minddet/models/centernet/src/resnet.py:139-178 --
+//   conv1 1x1 (Cin -> 64) + bn1 + relu -> conv2 3x3 (64 -> 64) + bn2 + relu -> conv3 1x1 (64 -> 256) + bn3, + residual, relu --
+// which md_conv2d runs as three launches that move 2048 B of activations per pixel through HBM (x read by conv1 AND again as the
+// residual, the two 64-channel intermediates written and re-read).  Measured r01/r02 (profiles/): those launches already run at
+// 5.2-5.8 TB/s of algorithmic traffic, i.e. at what the HBM gives -- only removing bytes makes the R50 / R101 stage-1 blocks
+// faster.  Here a workgroup owns an 8 x 16 block of output pixels of one image and keeps everything between x and y on the CU:
+//
+//   phase A  T1[10x18 halo px][64] = relu(W1 . x + b1), zero outside the image (the 3x3 conv's zero padding applies to T1);
+//            x streams through LDS in 64-channel chunks (LDS-DMA, two buffers, counted vmcnt, raw s_barrier), T1 stays in LDS
+//   phase B  T2[8x16 px][64] = relu(sum_taps W2[tap] . T1[shifted rows] + b2): the halo-reuse scheme of conv3x3_halo_kernel with
+//            the halo read from T1 instead of from HBM; only the 8 KiB weight slice of each tap is streamed (from L2)
+//   phase C  y[px][256] = relu(W3 . T2 + b3 + residual) in four 64-channel quarters through an 18 KiB LDS transpose image,
+//            whole-line NHWC stores; the residual is the block input (or a downsample conv's output) re-read from L2 / MALL.
+//
+// HBM traffic per pixel: 512 B in (+ the halo columns that miss L2) + 512 B out instead of 2048 B.  Per 128-pixel tile: 604
+// v_mfma_f32_32x32x16_bf16 (19.8 MFLOP) against 128 KiB of HBM traffic = 155 flop/B: the block is HBM-bound as long as the
+// matrix pipe runs above 33 % busy, which two resident workgroups per CU (80 KiB of LDS each) provide.
+//
+// LDS map (80 KiB): A [0,32K) phase A: W1 chunk a (8K) + x chunk a (24K) | B: W2 taps 0-3 / 5-8 | C: W3 (32K)
+//                   B [32K,56K) phase A: x chunk b | B: T1 | C: transpose image (18K)
+//                   C [56K,64K) phase A: W1 chunk b | B: W2 tap 4 | C: b3 (1K)
+//                   D [64K,80K) phase A / B: b1, b2 (512 B) | C: T2 (16K)
+// Tiles are [row][64 k] bf16 (128-B rows), the 16-B chunk index XOR-swizzled by (row >> 1) & 7 on the DMA's SOURCE chunk and on
+// the fragment reads (conflict-free ds_read_b128), as in conv.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "aot.h"
+
+namespace md {
+
+typedef __attribute__((ext_vector_type(8))) short bn_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float bn_f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int bn_u32x4;
+typedef float bn_f32x2 __attribute__((ext_vector_type(2)));
+
+struct BottleneckArgs {
+    const uint16_t *x;    // [N,H,W,Cin]
+    const uint16_t *w1;   // [64][Cin]
+    const uint16_t *w2;   // [64][576]  K = tap * 64 + ci
+    const uint16_t *w3;   // [256][64]
+    const uint16_t *res;  // [N,H,W,256] (the block input when Cin == 256)
+    const float *b1, *b3;   // b1: 128 floats = b1 | b2
+    uint16_t *y;          // [N,H,W,256]
+    int N, H, W, Cin, nch;            // nch = Cin / 64
+    int tiles_x, tiles_y, n_tiles, pt_per_xcd;
+    unsigned x_bytes, w1_bytes;
+    unsigned long long *dbg;   // MD_DIAG builds only
+};
+
+constexpr int BN_TH = 8, BN_TW = 16, BN_HW = BN_TW + 2, BN_HALO = (BN_TH + 2) * BN_HW;  // 180 halo pixels
+constexpr int BN_ROWB = 128;
+constexpr int BN_A = 0, BN_B = 32768, BN_C = 57344, BN_D = 65536, BN_LDS = 81920;
+constexpr int BN_ES = 144;  // transpose image row stride (64 channels * 2 B + 16)
+
+__device__ __forceinline__ unsigned bn_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ unsigned bn_pk_relu(unsigned v) {
+    unsigned r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ int bn_swz(int row, int chunk) { return row * BN_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// MD_DIAG build (tools/bottleneck_stamps.py): cycle stamps of one mid-grid workgroup, written to a buffer of their own
+#ifdef MD_DIAG
+#define BN_STAMP(I) do { if (a.dbg) { __builtin_amdgcn_sched_barrier(0); stp[I] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define BN_STAMP(I) do { } while (0)
+#endif
+#define BN_BAR_RAW()                                              \
+    do {                                                          \
+        __builtin_amdgcn_sched_barrier(0);                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+        __builtin_amdgcn_s_barrier();                             \
+        __builtin_amdgcn_sched_barrier(0);                        \
+    } while (0)
+
+// IDENT: the residual is the block input itself (Cin == 256): output quarter q's residual channels are exactly x chunk q, so each
+// thread copies its 16-B pieces out of the chunk while it sits in LDS (no second trip to L2 / HBM, no latency in phase C).
+// 8 waves per workgroup, two workgroups per CU = 4 waves per SIMD: r02 stamps (tools/bottleneck_stamps.py) of the 4-wave form showed
+// every phase latency-bound at 2 waves per SIMD (27 % MFMA-busy, HBM traffic already at the algorithmic minimum).
+template <bool IDENT>
+__global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr unsigned OOR = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wc = wave & 1, wq = wave >> 1;   // cout fragment (32 rows) / pixel-row fragment group of this wave
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pt = xcd * a.pt_per_xcd + slot;
+    if (pt >= a.n_tiles) return;
+    const int tx = pt % a.tiles_x, ty = (pt / a.tiles_x) % a.tiles_y, n = pt / (a.tiles_x * a.tiles_y);
+    const int y0 = ty * BN_TH, x0 = tx * BN_TW;
+#ifdef MD_DIAG
+    unsigned long long stp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    BN_STAMP(0);
+
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w1, 0, a.w1_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2, 0, 64 * 576 * 2, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w3, 0, 256 * 64 * 2, 0x00020000);
+
+    // ---- staging maps.  One wave instruction = 8 rows x 128 B; lane -> (row = 8 * piece + lane / 8, physical chunk = lane & 7).
+    // 64-row weight tiles = 8 pieces: wave w stages piece w.  x halo = 24 pieces: wave w stages pieces w, w + 8, w + 16.
+    const int srow = lane >> 3;
+    const int wrow = wave * 8 + srow;
+    const int wchunk = (lane & 7) ^ ((wrow >> 1) & 7);
+    unsigned h_off[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int r = (wave + 8 * j) * 8 + srow;
+        const int hy = r / BN_HW, hx = r - hy * BN_HW;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const int lchunk = (lane & 7) ^ ((r >> 1) & 7);
+        const bool ok = r < BN_HALO && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        h_off[j] = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + lchunk * 8) * 2) : OOR;
+    }
+    // biases: requested now (after the address arithmetic above: hipcc otherwise parks a load's destination in the don't-care half
+    // of a 64-bit multiply-add operand and waits for the load in front of the first DMA), parked in LDS later (b1 | b2 in region D,
+    // b3 in region C)
+    __builtin_amdgcn_sched_barrier(0);
+    const float b3_early = a.b3[tid & 255];
+    const float b12_early = a.b1[tid & 127];   // b1 | b2 are 64 + 64 consecutive floats (the host packs them so)
+    __builtin_amdgcn_sched_barrier(0);
+    auto dma_chunk_a = [&](int kt, int buf) {   // phase A: chunk kt of W1 (64 x 64) and of the x halo (192 x 64): 4 instructions per wave
+        char *Wd = smem + (buf ? BN_C : BN_A), *Xd = smem + (buf ? BN_B : BN_A + 8192);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (lds_void *)(Wd + wave * 1024), 16, (wrow * a.Cin + wchunk * 8) * 2, kt * 128, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(Xd + (wave + 8 * j) * 1024), 16, (int)h_off[j], kt * 128, 0, 0);
+    };
+    auto dma_tap = [&](int t, char *dst) {      // phase B: W2[:, tap t] (64 x 64): 1 instruction per wave
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (lds_void *)(dst + wave * 1024), 16, (wrow * 576 + wchunk * 8) * 2, t * 128, 0, 0);
+    };
+
+    // ---- phase A: T1 = relu(W1 . x + b1) on the 192 halo rows = 2 cout x 6 row fragments of 32 x 32: wave (wc, wq) owns row
+    // fragments wq and, for wq < 2, wq + 4
+    const bool two = wq < 2;
+    bn_f32x16 acc1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
+    // this thread's two 16-B pieces of a quarter's [128 px][64 ch] output image: e = tid + 512 it -> pixel e >> 3, chunk e & 7
+    bn_u32x4 rres[4][2];
+    int res_lds[2];   // IDENT: where that piece of the residual sits in an x chunk (halo row of the centre pixel, swizzled chunk)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = tid + 512 * it, p = e >> 3, cc = e & 7;
+        const int r = ((p >> 4) + 1) * BN_HW + (p & 15) + 1;
+        res_lds[it] = bn_swz(r, cc);
+    }
+    dma_chunk_a(0, 0);
+    if (a.nch > 1) dma_chunk_a(1, 1);
+    float *bias12 = reinterpret_cast<float *>(smem + BN_D);
+    if (tid < 128) bias12[tid] = b12_early;   // the load is older than every DMA: waiting for it drains nothing
+    for (int kt = 0; kt < a.nch; ++kt) {
+        // this wave's share of chunk kt has landed; the 4 younger DMAs (chunk kt + 1, or the W2 taps requested below) stay in flight
+        if (kt + 1 < a.nch || a.nch >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BN_BAR_RAW();
+        if (kt == 0) BN_STAMP(1);
+        const char *Wt = smem + ((kt & 1) ? BN_C : BN_A), *Xt = smem + ((kt & 1) ? BN_B : BN_A + 8192);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bn_bf16x8 fa = *reinterpret_cast<const bn_bf16x8 *>(Wt + bn_swz(32 * wc + lr, 2 * kk + lh));
+            const bn_bf16x8 fb0 = *reinterpret_cast<const bn_bf16x8 *>(Xt + bn_swz(32 * wq + lr, 2 * kk + lh));
+            acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb0, acc1[0], 0, 0, 0);
+            if (two) {
+                const bn_bf16x8 fb1 = *reinterpret_cast<const bn_bf16x8 *>(Xt + bn_swz(32 * (wq + 4) + lr, 2 * kk + lh));
+                acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb1, acc1[1], 0, 0, 0);
+            }
+        }
+        if constexpr (IDENT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q == kt) {
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) rres[q][it] = *reinterpret_cast<const bn_u32x4 *>(Xt + res_lds[it]);
+                }
+        }
+        BN_BAR_RAW();   // every wave has finished reading this buffer
+        if (kt + 2 < a.nch) dma_chunk_a(kt + 2, kt & 1);
+        else if (a.nch >= 3 && kt == a.nch - 2) {
+            // buffer a (region A) has seen its last chunk: W2 taps 0-3 are requested now and land behind the last chunk's MFMAs
+            // (nch is even here: chunk nch - 2 used buffer a; the host side admits nch = 1 or 4)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dma_tap(t, smem + BN_A + t * 8192);
+        }
+    }
+    BN_STAMP(2);
+    // W2 taps 0-3 -> region A (if not requested above), tap 4 -> region C (free: the loop's last barrier has passed)
+    if (a.nch < 3) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dma_tap(t, smem + BN_A + t * 8192);
+    }
+    dma_tap(4, smem + BN_C);
+    {   // T1 -> region B: bias, ReLU, zero outside the image, bf16; lane = halo row, 4 consecutive channels per register group
+        char *T1 = smem + BN_B;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j == 1 && !two) break;
+            const int r = 32 * (wq + 4 * j) + lr;
+            const int hy = r / BN_HW, hx = r - hy * BN_HW;
+            const bool ok = r < BN_HALO && (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c_local = 32 * wc + 8 * g + 4 * lh;
+                const float4 bv = *reinterpret_cast<const float4 *>(bias12 + c_local);
+                uint2 pk;
+                pk.x = bn_pk_relu(bn_pk_bf16(acc1[j][4 * g + 0] + bv.x, acc1[j][4 * g + 1] + bv.y));
+                pk.y = bn_pk_relu(bn_pk_bf16(acc1[j][4 * g + 2] + bv.z, acc1[j][4 * g + 3] + bv.w));
+                if (!ok) pk.x = pk.y = 0u;
+                *reinterpret_cast<uint2 *>(T1 + r * BN_ROWB + (((4 * wc + g) ^ ((r >> 1) & 7)) << 4) + 8 * lh) = pk;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    BN_STAMP(3);
+
+    // ---- phase B: T2 = relu(conv3x3(T1) + b2) = 2 cout x 4 pixel fragments: wave (wc, wq) owns couts 32 wc.., pixels 32 wq..
+    bn_f32x16 acc2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+    const int pB = 32 * wq + lr;
+    const int r0 = (pB >> 4) * BN_HW + (pB & 15);   // halo row of this lane's pixel for tap (0, 0)
+    auto tap_mfma = [&](int t, const char *Wt) {
+        const char *T1 = smem + BN_B;
+        const int r = r0 + (t / 3) * BN_HW + (t % 3);
+        const int sw = (r >> 1) & 7;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bn_bf16x8 fb = *reinterpret_cast<const bn_bf16x8 *>(T1 + r * BN_ROWB + (((2 * kk + lh) ^ sw) << 4));
+            const bn_bf16x8 fa = *reinterpret_cast<const bn_bf16x8 *>(Wt + bn_swz(32 * wc + lr, 2 * kk + lh));
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc2, 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < 4; ++t) tap_mfma(t, smem + BN_A + t * 8192);
+    tap_mfma(4, smem + BN_C);
+    __syncthreads();   // taps 0-4 consumed
+    BN_STAMP(4);
+#pragma unroll
+    for (int t = 5; t < 9; ++t) dma_tap(t, smem + BN_A + (t - 5) * 8192);
+    if (tid < 256) reinterpret_cast<float *>(smem + BN_C)[tid] = b3_early;   // b3 -> region C (tap 4 is consumed)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    BN_STAMP(5);
+#pragma unroll
+    for (int t = 5; t < 9; ++t) tap_mfma(t, smem + BN_A + (t - 5) * 8192);
+    float4 bv2[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bv2[g] = *reinterpret_cast<const float4 *>(bias12 + 64 + 32 * wc + 8 * g + 4 * lh);
+    __syncthreads();   // every wave is done with T1, the tap buffers and b2
+    BN_STAMP(6);
+    // W3 (256 x 64) -> region A: 32 pieces, wave w stages pieces w + 8j
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave + 8 * j) * 8 + srow;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w3, (lds_void *)(smem + BN_A + (wave + 8 * j) * 1024), 16,
+                                                 (row * 64 + ((lane & 7) ^ ((row >> 1) & 7)) * 8) * 2, 0, 0, 0);
+    }
+    {   // T2 -> region D
+        char *T2 = smem + BN_D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 pk;
+            pk.x = bn_pk_relu(bn_pk_bf16(acc2[4 * g + 0] + bv2[g].x, acc2[4 * g + 1] + bv2[g].y));
+            pk.y = bn_pk_relu(bn_pk_bf16(acc2[4 * g + 2] + bv2[g].z, acc2[4 * g + 3] + bv2[g].w));
+            *reinterpret_cast<uint2 *>(T2 + pB * BN_ROWB + (((4 * wc + g) ^ ((pB >> 1) & 7)) << 4) + 8 * lh) = pk;
+        }
+    }
+    // this thread's two 16-B pieces of a quarter's image in global memory
+    long long g_off[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = tid + 512 * it, p = e >> 3, cc = e & 7;
+        const int yy = y0 + (p >> 4), xx = x0 + (p & 15);
+        g_off[it] = (yy < a.H && xx < a.W) ? ((long long)(n * a.H + yy) * a.W + xx) * 256 + cc * 8 : -1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    BN_STAMP(7);
+
+    // ---- phase C: y = relu(W3 . T2 + b3 + residual), 64 output channels at a time = 2 cout x 4 pixel fragments per quarter
+    const float *bias3 = reinterpret_cast<const float *>(smem + BN_C);
+    char *E = smem + BN_B;
+    if constexpr (!IDENT) {   // a separate residual tensor: all 8 pieces requested now, behind every DMA of the tile
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                rres[q][it] = (bn_u32x4){0u, 0u, 0u, 0u};
+                if (g_off[it] >= 0) rres[q][it] = __builtin_nontemporal_load(reinterpret_cast<const bn_u32x4 *>(a.res + g_off[it] + 64 * q));
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bn_f32x16 acc3;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bn_bf16x8 fa = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_A + bn_swz(64 * q + 32 * wc + lr, 2 * kk + lh));
+            const bn_bf16x8 fb = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_D + bn_swz(32 * wq + lr, 2 * kk + lh));
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc3, 0, 0, 0);
+        }
+        if (q == 1) BN_STAMP(13);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c_local = 32 * wc + 8 * g + 4 * lh;
+            const float4 bv = *reinterpret_cast<const float4 *>(bias3 + 64 * q + c_local);
+            uint2 pk;
+            pk.x = bn_pk_bf16(acc3[4 * g + 0] + bv.x, acc3[4 * g + 1] + bv.y);
+            pk.y = bn_pk_bf16(acc3[4 * g + 2] + bv.z, acc3[4 * g + 3] + bv.w);
+            *reinterpret_cast<uint2 *>(E + pB * BN_ES + c_local * 2) = pk;
+        }
+        BN_BAR_RAW();   // raw barriers in this loop: __syncthreads() would wait for the previous quarter's stores to COMPLETE (vmcnt 0)
+        if (q == 1) BN_STAMP(14);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            if (g_off[it] < 0) continue;
+            const int e = tid + 512 * it;
+            bn_u32x4 v = *reinterpret_cast<const bn_u32x4 *>(E + (e >> 3) * BN_ES + (e & 7) * 16);
+            const bn_u32x4 rv = rres[q][it];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bn_f32x2 sum = (bn_f32x2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)} +
+                                     (bn_f32x2){__uint_as_float(rv[k] << 16), __uint_as_float(rv[k] & 0xffff0000u)};
+                v[k] = bn_pk_relu(bn_pk_bf16(sum.x, sum.y));
+            }
+            __builtin_nontemporal_store(v, reinterpret_cast<bn_u32x4 *>(a.y + g_off[it] + 64 * q));
+        }
+        if (q == 1) BN_STAMP(15);
+        BN_BAR_RAW();      // the image is rewritten by the next quarter
+        BN_STAMP(8 + q);
+    }
+#ifdef MD_DIAG
+    if (a.dbg && blockIdx.x == (gridDim.x / 2) && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stp[12] = __builtin_readcyclecounter();
+        for (int i = 0; i < 16; ++i) a.dbg[i] = stp[i];
+    }
+#endif
+}
+
+}  // namespace md
+
+using namespace md;
+
+#ifdef MD_DIAG
+static unsigned long long *g_bn_stamp_buf = nullptr;
+extern "C" int md_diag_set_bn_stamp_buffer(void *p) { g_bn_stamp_buf = (unsigned long long *)p; return MD_OK; }
+#endif
+
+// in : x[N,H,W,Cin] bf16 (Cin = 64 or 256), w1[64,Cin] bf16, b12[128] f32 (= b1 | b2), w2[64,576] bf16 (K = tap*64 + ci),
+//      w3[256,64] bf16, b3[256] f32, residual[N,H,W,256] bf16 or NULL (= x, needs Cin == 256)
+// out: y[N,H,W,256] bf16
+extern "C" int md_bottleneck(MD_AOT_ARGS) {
+    if (nparam != 8) return MD_ERR_NPARAM;
+    if (!params || !ndims || !shapes) return MD_ERR_ARG;
+    for (int i : {0, 1, 3, 4, 7})
+        if (!dtype_is(dtypes, i, "bfloat16")) return MD_ERR_ARG;
+    for (int i : {2, 5})
+        if (!dtype_is(dtypes, i, "float32")) return MD_ERR_ARG;
+    if (params[6] && !dtype_is(dtypes, 6, "bfloat16")) return MD_ERR_ARG;
+    if (ndims[0] != 4 || ndims[7] != 4 || ndims[1] != 2 || ndims[3] != 2 || ndims[4] != 2) return MD_ERR_ARG;
+    const int64_t N = shapes[0][0], H = shapes[0][1], W = shapes[0][2], Cin = shapes[0][3];
+    if ((Cin != 64 && Cin != 256) || shapes[1][0] != 64 || shapes[1][1] != Cin || shapes[3][0] != 64 || shapes[3][1] != 576 ||
+        shapes[4][0] != 256 || shapes[4][1] != 64 || numel(ndims, shapes, 2) != 128 || numel(ndims, shapes, 5) < 256)
+        return MD_ERR_ARG;
+    if (shapes[7][0] != N || shapes[7][1] != H || shapes[7][2] != W || shapes[7][3] != 256) return MD_ERR_ARG;
+    if (params[6]) {
+        if (ndims[6] != 4 || numel(ndims, shapes, 6) != N * H * W * 256) return MD_ERR_ARG;
+    } else if (Cin != 256) return MD_ERR_ARG;
+    if (N * H * W == 0) return MD_OK;
+    for (int i : {0, 1, 2, 3, 4, 5, 7})
+        if (!params[i]) return MD_ERR_ARG;
+    if (H > 32000 || W > 32000) return MD_ERR_SIZE;
+    const long long x_img = H * W * Cin * 2;
+    if (x_img >= 0x7fff0000LL) return MD_ERR_SIZE;
+    // 32-bit DMA offsets: run the batch as image chunks whose x tensor stays below 2 GiB (as md_conv2d does)
+    const long long per = 0x7fff0000LL / x_img < N ? 0x7fff0000LL / x_img : N;
+    const int tiles_x = (int)((W + BN_TW - 1) / BN_TW), tiles_y = (int)((H + BN_TH - 1) / BN_TH);
+    auto k = params[6] ? bottleneck64_kernel<false> : bottleneck64_kernel<true>;
+    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, BN_LDS) != hipSuccess) return MD_ERR_HIP;
+    for (long long n0 = 0; n0 < N; n0 += per) {
+        const long long nn = N - n0 < per ? N - n0 : per;
+        BottleneckArgs a;
+        a.x = (const uint16_t *)params[0] + n0 * H * W * Cin;
+        a.w1 = (const uint16_t *)params[1]; a.b1 = (const float *)params[2];
+        a.w2 = (const uint16_t *)params[3];
+        a.w3 = (const uint16_t *)params[4]; a.b3 = (const float *)params[5];
+        a.res = (params[6] ? (const uint16_t *)params[6] : (const uint16_t *)params[0]) + n0 * H * W * 256;
+        a.y = (uint16_t *)params[7] + n0 * H * W * 256;
+        a.N = (int)nn; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.nch = (int)(Cin / 64);
+        a.tiles_x = tiles_x; a.tiles_y = tiles_y;
+        const long long n_tiles = nn * tiles_x * tiles_y;
+        if (n_tiles > 0x7fffffffLL / 8) return MD_ERR_SIZE;
+        a.n_tiles = (int)n_tiles;
+        a.pt_per_xcd = (a.n_tiles + 7) / 8;
+        a.x_bytes = (unsigned)(nn * x_img);
+        a.w1_bytes = (unsigned)(64 * Cin * 2);
+        a.dbg = nullptr;
+#ifdef MD_DIAG
+        a.dbg = g_bn_stamp_buf;
+#endif
+        hipLaunchKernelGGL(k, dim3((unsigned)(a.pt_per_xcd * 8)), dim3(512), BN_LDS, (hipStream_t)stream, a);
+    }
+    md_note_conv_kernel(MD_CONV_KERNEL_BOTTLENECK);
+    MD_HIP_TRY(hipGetLastError());
+    return MD_OK;
+}

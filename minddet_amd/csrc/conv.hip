@@ -1214,6 +1214,7 @@ using namespace md;
 // Required weight padding for a given Cout (the tile the dispatcher will pick): exported so the
 // host packer pads consistently.
 extern "C" int md_conv2d_last_kernel(void) { return g_last_kernel; }
+namespace md { void md_note_conv_kernel(int id) { g_last_kernel = id; } }
 extern "C" long long md_conv2d_set_chunk_limit(long long bytes) {
     const long long old = g_chunk_limit;
     g_chunk_limit = bytes > 0 && bytes < 0x7fff0000LL ? bytes : 0x7fff0000LL;

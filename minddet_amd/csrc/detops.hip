@@ -86,7 +86,8 @@ struct Anchor3dRangeArgs {
     float rot[8];
 };
 __device__ __forceinline__ float linspace_at(const LinAxis &ax, int i, int mode) {
-    if (ax.n > 1 && i == ax.n - 1) return ax.hi;
+    if (ax.n == 1) return ax.lo;
+    if (i == ax.n - 1) return ax.hi;
     if (ax.step == 0.f) {   // numpy's any_step_zero branch: (i / div) * delta + lo
         const float delta = ax.hi - ax.lo;
         if (mode == 0) return ((float)i / (float)(ax.n - 1)) * delta + ax.lo;

@@ -20,6 +20,9 @@ from .registry import BACKBONES, DETECTORS, HEADS, NECKS, ROI_HEAD, build_backbo
 # per-level proposal selection (slice, top-k, decode) on a side HIP stream behind the level's conv, joined before the NMS: +0.4 % on
 # the benchmark (same-box 1 856 -> 1 863 images/s); 0 = everything on one stream (A/B)
 RPN_OVERLAP = os.environ.get("MD_RPN_OVERLAP", "1") == "1"
+# stride-1 bottleneck blocks with 64 mid channels (ResNet-50 / 101 stage 1) as ONE md_bottleneck launch instead of three md_conv2d
+# launches (bit-identical results; MD_FUSE_BLOCKS=0 keeps the layer-by-layer path for A/B)
+FUSE_BLOCKS = os.environ.get("MD_FUSE_BLOCKS", "1") == "1"
 RPN_FUSED_HEAD = os.environ.get("MD_RPN_FUSED", "1") == "1"  # 0: two md_conv2d launches per level (A/B)
 
 
@@ -110,11 +113,18 @@ class Bottleneck:
         self.conv2 = ConvModule(init, planes, planes, 3, stride, 1)
         self.conv3 = ConvModule(init, planes, planes * 4, 1, relu=True)  # ReLU after the residual add
         self.downsample = downsample
+        self._fused = False
 
     def modules(self):
         return [self.conv1, self.conv2, self.conv3] + ([self.downsample] if self.downsample else [])
 
     def __call__(self, x):
+        if FUSE_BLOCKS:
+            if self._fused is False:   # packed on first use (the convs are packed by ResNet.to)
+                self._fused = nn_ops.pack_bottleneck(self.conv1.packed, self.conv2.packed, self.conv3.packed)
+            if self._fused is not None:
+                # one launch for the whole block (md_bottleneck): x is read once, the 64-channel intermediates stay in LDS
+                return nn_ops.bottleneck(x, self._fused, residual=self.downsample(x) if self.downsample is not None else None)
         residual = self.downsample(x) if self.downsample is not None else x
         return self.conv3(self.conv2(self.conv1(x)), residual=residual)
 

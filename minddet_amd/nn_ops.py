@@ -138,6 +138,45 @@ def conv2d_head(x, pc, pc2, variant=None):
     return y2
 
 
+class PackedBottleneck:
+    """The three packed convs of a stride-1 bottleneck block with 64 mid channels, as md_bottleneck consumes them."""
+
+    def __init__(self, pc1, pc2, pc3):
+        self.cin, self.cout = pc1.cin, pc3.cout
+        self.w1, self.w2, self.w3 = pc1.w, pc2.w, pc3.w
+        self.b12 = torch.cat([pc1.bias[:64], pc2.bias[:64]]).contiguous()
+        self.b3 = pc3.bias
+        self.macs_per_pixel = pc1.cin_real * 64 + 9 * 64 * 64 + 64 * 256
+
+    def flops_bytes(self, n, h, w, with_residual_tensor=False):
+        """algorithmic flops and bytes of the block as ONE op: x read once, y written once (+ a separate residual tensor)"""
+        px = n * h * w
+        byts = 2.0 * (px * (self.cin + 256 + (256 if with_residual_tensor else 0)) + self.w1.numel() + self.w2.numel() + self.w3.numel())
+        return 2.0 * px * self.macs_per_pixel, byts
+
+
+def pack_bottleneck(pc1, pc2, pc3):
+    """-> PackedBottleneck if (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + residual) is the shape md_bottleneck fuses, else None."""
+    ok = (pc1.kh == 1 and pc1.stride == 1 and pc1.pad == 0 and pc1.relu == 1 and pc1.cout == 64 and pc1.cin in (64, 256) and
+          tuple(pc1.w.shape) == (64, pc1.cin) and
+          pc2.kh == 3 and pc2.kw == 3 and pc2.stride == 1 and pc2.pad == 1 and pc2.relu == 1 and pc2.cin == 64 and pc2.cout == 64 and
+          tuple(pc2.w.shape) == (64, 576) and
+          pc3.kh == 1 and pc3.stride == 1 and pc3.pad == 0 and pc3.relu == 1 and pc3.cin == 64 and pc3.cout == 256 and
+          tuple(pc3.w.shape) == (256, 64))
+    return PackedBottleneck(pc1, pc2, pc3) if ok else None
+
+
+def bottleneck(x, blk, residual=None, out=None):
+    """y = relu(conv3(relu(conv2(relu(conv1(x))))) + residual) in one md_bottleneck launch; residual None = x (identity block)."""
+    n, h, w, c = x.shape
+    if c != blk.cin:
+        raise _lib.MindDetHipError(f"bottleneck: input has {c} channels, block packed for {blk.cin}")
+    if out is None:
+        out = torch.empty((n, h, w, 256), dtype=torch.bfloat16, device=x.device)
+    _lib.call("md_bottleneck", [x, blk.w1, blk.b12, blk.w2, blk.w3, blk.b3, residual, out])
+    return out
+
+
 class PackedConvT:
     """A transposed conv as s*s sub-pixel convs on the MFMA kernel (one launch per output parity)."""
 

@@ -322,3 +322,109 @@ def test_diagnostic_variants_are_not_in_the_product_library():
     assert not hasattr(_lib.lib(), "md_diag_set_stamp_buffer") and not hasattr(_lib.lib(), "md_conv2d_chain")
 
 
+
+
+BOTTLENECK_CASES = [
+    # name, N, H, W, Cin, downsample
+    ("identity_whole_tiles", 2, 24, 48, 256, False),
+    ("identity_ragged", 1, 19, 23, 256, False),
+    ("identity_one_tile", 1, 8, 16, 256, False),
+    ("identity_smaller_than_a_tile", 2, 5, 7, 256, False),
+    ("first_block_downsample", 2, 24, 40, 64, True),
+    ("first_block_ragged", 1, 13, 37, 64, True),
+    ("stage1_like", 3, 50, 84, 256, False),
+]
+
+
+def _bottleneck_modules(cin, seed, downsample):
+    from minddet_amd import nn_ops
+
+    g = torch.Generator().manual_seed(seed)
+
+    def bn(c):
+        return (torch.rand((c,), generator=g) + 0.5, torch.randn((c,), generator=g) * 0.1, torch.randn((c,), generator=g) * 0.1,
+                torch.rand((c,), generator=g) + 0.5, 1e-5)
+
+    w1 = torch.randn((64, cin, 1, 1), generator=g) * (2.0 / cin) ** 0.5
+    w2 = torch.randn((64, 64, 3, 3), generator=g) * (2.0 / 576) ** 0.5
+    w3 = torch.randn((256, 64, 1, 1), generator=g) * (2.0 / 64) ** 0.5
+    pcs = [nn_ops.pack_conv(w1, bn=bn(64), relu=True).to(DEV), nn_ops.pack_conv(w2, bn=bn(64), stride=1, pad=1, relu=True).to(DEV),
+           nn_ops.pack_conv(w3, bn=bn(256), relu=True).to(DEV)]
+    pd = nn_ops.pack_conv(torch.randn((256, cin, 1, 1), generator=g) * (1.0 / cin) ** 0.5, bn=bn(256), relu=False).to(DEV) if downsample else None
+    return pcs, pd, g
+
+
+@pytest.mark.parametrize("cfg", BOTTLENECK_CASES, ids=lambda c: c[0])
+def test_fused_bottleneck_equals_three_launches(cfg):
+    """md_bottleneck (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + residual + ReLU in one launch, intermediates in LDS) against the three
+    md_conv2d launches it replaces: same operands, same K order, same bf16 rounding points -> bit-identical; and against fp32 torch."""
+    from minddet_amd import _lib, nn_ops
+
+    name, N, H, W, Cin, ds = cfg
+    (pc1, pc2, pc3), pd, g = _bottleneck_modules(Cin, len(name) * 13 + H, ds)
+    blk = nn_ops.pack_bottleneck(pc1, pc2, pc3)
+    assert blk is not None
+    x = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16).to(DEV)
+    res = nn_ops.conv2d(x, pd) if ds else x
+    ref = nn_ops.conv2d(nn_ops.conv2d(nn_ops.conv2d(x, pc1), pc2), pc3, residual=res)
+    y = nn_ops.bottleneck(x, blk, residual=res if ds else None)
+    assert _lib.lib().md_conv2d_last_kernel() == 7
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref), (y.float() - ref.float()).abs().max().item()
+    # fp32 torch on the bf16-rounded operands (bf16 rounding of the two intermediates reproduced)
+    xf = x.float().cpu().permute(0, 3, 1, 2)
+
+    def conv(t, pc, k, pad):
+        w = pc.w[:pc.cout].float().cpu().view(pc.cout, k, k, -1).permute(0, 3, 1, 2)
+        return F.conv2d(t, w, pc.bias[:pc.cout].cpu(), padding=pad)
+
+    t1 = torch.relu(conv(xf, pc1, 1, 0)).to(torch.bfloat16).float()
+    t2 = torch.relu(conv(t1, pc2, 3, 1)).to(torch.bfloat16).float()
+    t3 = conv(t2, pc3, 1, 0).to(torch.bfloat16).float() + res.float().cpu().permute(0, 3, 1, 2)
+    t3 = torch.relu(t3).permute(0, 2, 3, 1)
+    err = (y.float().cpu() - t3).abs()
+    assert (err <= 2e-2 * t3.abs() + 3e-2).all(), err.max().item()
+
+
+def test_fused_bottleneck_argument_checks_and_determinism():
+    from minddet_amd import _lib, nn_ops
+
+    (pc1, pc2, pc3), pd, g = _bottleneck_modules(256, 5, False)
+    blk = nn_ops.pack_bottleneck(pc1, pc2, pc3)
+    x = torch.randn((2, 16, 32, 256), generator=g).to(torch.bfloat16).to(DEV)
+    y1, y2 = nn_ops.bottleneck(x, blk), nn_ops.bottleneck(x, blk)
+    assert torch.equal(y1, y2)
+    assert nn_ops.bottleneck(torch.zeros((0, 16, 32, 256), dtype=torch.bfloat16, device=DEV), blk).shape == (0, 16, 32, 256)
+    with pytest.raises(_lib.MindDetHipError, match="rc=2"):      # an identity block needs 256 input channels
+        (p1, p2, p3), _, _ = _bottleneck_modules(64, 6, False)
+        nn_ops.bottleneck(torch.zeros((1, 8, 16, 64), dtype=torch.bfloat16, device=DEV), nn_ops.pack_bottleneck(p1, p2, p3))
+    with pytest.raises(_lib.MindDetHipError, match="rc=2"):      # output shape
+        nn_ops.bottleneck(x, blk, out=torch.zeros((2, 16, 32, 128), dtype=torch.bfloat16, device=DEV))
+    with pytest.raises(_lib.MindDetHipError, match="rc=2"):      # residual shape
+        nn_ops.bottleneck(x, blk, residual=torch.zeros((2, 16, 32, 64), dtype=torch.bfloat16, device=DEV))
+    # blocks md_bottleneck does not take are not packed: the graph keeps the three-launch path for them
+    p128 = nn_ops.pack_conv(torch.randn((128, 512, 1, 1)) * 0.05, relu=True).to(DEV)
+    assert nn_ops.pack_bottleneck(p128, pc2, pc3) is None
+    ps2 = nn_ops.pack_conv(torch.randn((64, 64, 3, 3)) * 0.05, stride=2, pad=1, relu=True).to(DEV)
+    assert nn_ops.pack_bottleneck(pc1, ps2, pc3) is None
+
+
+def test_resnet_with_fused_blocks_equals_layer_by_layer():
+    from minddet_amd import graphs
+
+    bb = graphs.ResNet(depth=50, base_width=64, layers=[3, 1, 1, 1], seed=9).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    x8 = torch.zeros((2, 96, 160, 8))
+    x8[..., :3] = torch.randn((2, 96, 160, 3), generator=g)
+    xb = x8.to(torch.bfloat16).to(DEV)
+    old = graphs.FUSE_BLOCKS
+    try:
+        graphs.FUSE_BLOCKS = True
+        fused = bb(xb)
+        assert all(b._fused is not None for b in bb.stages[0]) and all(b._fused in (None, False) for st in bb.stages[1:] for b in st)
+        graphs.FUSE_BLOCKS = False
+        plain = bb(xb)
+    finally:
+        graphs.FUSE_BLOCKS = old
+    for f, p in zip(fused, plain):
+        assert torch.equal(f, p)
