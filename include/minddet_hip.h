@@ -188,7 +188,10 @@ int md_conv2d_head(MD_AOT_ARGS);
  * intermediates), so the result equals the three-launch path bit for bit.
  * in : x[N,H,W,Cin] bf16 (Cin = 64 or 256), w1[64,Cin] bf16, b12[128] f32 (conv1's 64 biases followed by conv2's),
  *      w2[64,576] bf16 (K = tap*64 + ci), w3[256,64] bf16, b3[256] f32 (weights as md_conv2d packs them, BN folded),
- *      residual[N,H,W,256] bf16, or a NULL pointer = x itself (identity block, needs Cin == 256)
+ *      residual[N,H,W,256] bf16 | NULL, wd[256,64] bf16 | NULL, bd[256] f32 | NULL -- the residual source is, in this order:
+ *        wd / bd given (Cin == 64, residual NULL): the block's 1x1 downsample conv bf16(wd . x + bd), computed in the same launch
+ *          from the x tile in LDS (the first block of a stage, resnet.py _make_layer: no downsample launch, no 512 B / pixel tensor);
+ *        residual given: that tensor;   neither (Cin == 256): x itself (identity block).
  * out: y[N,H,W,256] bf16.   extra: unused. */
 int md_bottleneck(MD_AOT_ARGS);
 

@@ -43,6 +43,8 @@ struct BottleneckArgs {
     const uint16_t *w3;   // [256][64]
     const uint16_t *res;  // [N,H,W,256] (the block input when Cin == 256)
     const float *b1, *b3;   // b1: 128 floats = b1 | b2
+    const uint16_t *wd;   // MODE 2: the downsample conv's [256][64] weights
+    const float *bd;      // MODE 2: its 256 biases
     uint16_t *y;          // [N,H,W,256]
     int N, H, W, Cin, nch;            // nch = Cin / 64
     int tiles_x, tiles_y, n_tiles, pt_per_xcd;
@@ -81,11 +83,17 @@ __device__ __forceinline__ int bn_swz(int row, int chunk) { return row * BN_ROWB
         __builtin_amdgcn_sched_barrier(0);                        \
     } while (0)
 
-// IDENT: the residual is the block input itself (Cin == 256): output quarter q's residual channels are exactly x chunk q, so each
-// thread copies its 16-B pieces out of the chunk while it sits in LDS (no second trip to L2 / HBM, no latency in phase C).
+// MODE 0: the residual is the block input itself (Cin == 256): output quarter q's residual channels are exactly x chunk q, so each
+//         thread copies its 16-B pieces out of the chunk while it sits in LDS (no second trip to L2 / HBM, no latency in phase C).
+// MODE 1: the residual is a separate [N,H,W,256] tensor, requested behind the last DMA of the tile.
+// MODE 2: the residual is the block's 1x1 downsample conv of x (Cin == 64: the first block of a stage, resnet.py:214-224 /
+//         _make_layer): Wd (32 KiB) is staged beside the one x chunk and phase A also computes bf16(Wd . x + bd) for the tile's 128
+//         centre pixels -- each wave exactly the (cout fragment, pixel fragment) tiles it owns again in phase C, so the values stay
+//         in 32 registers in accumulator layout; neither the downsample launch nor its 512 B / pixel output exist any more.
+// All three round where the layer-by-layer path rounds (conv3 -> bf16, residual -> bf16, sum -> bf16): bit-identical to it.
 // 8 waves per workgroup, two workgroups per CU = 4 waves per SIMD: r02 stamps (tools/bottleneck_stamps.py) of the 4-wave form showed
 // every phase latency-bound at 2 waves per SIMD (27 % MFMA-busy, HBM traffic already at the algorithmic minimum).
-template <bool IDENT>
+template <int MODE>
 __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) {
     typedef __attribute__((address_space(3))) void lds_void;
     constexpr unsigned OOR = 0x80000000u;
@@ -108,6 +116,7 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
     __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w1, 0, a.w1_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2, 0, 64 * 576 * 2, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w3, 0, 256 * 64 * 2, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_wd = __builtin_amdgcn_make_buffer_rsrc((void *)(MODE == 2 ? a.wd : a.w3), 0, 256 * 64 * 2, 0x00020000);
 
     // ---- staging maps.  One wave instruction = 8 rows x 128 B; lane -> (row = 8 * piece + lane / 8, physical chunk = lane & 7).
     // 64-row weight tiles = 8 pieces: wave w stages piece w.  x halo = 24 pieces: wave w stages pieces w, w + 8, w + 16.
@@ -130,6 +139,8 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
     __builtin_amdgcn_sched_barrier(0);
     const float b3_early = a.b3[tid & 255];
     const float b12_early = a.b1[tid & 127];   // b1 | b2 are 64 + 64 consecutive floats (the host packs them so)
+    float bd_early = 0.f;
+    if constexpr (MODE == 2) bd_early = a.bd[tid & 255];
     __builtin_amdgcn_sched_barrier(0);
     auto dma_chunk_a = [&](int kt, int buf) {   // phase A: chunk kt of W1 (64 x 64) and of the x halo (192 x 64): 4 instructions per wave
         char *Wd = smem + (buf ? BN_C : BN_A), *Xd = smem + (buf ? BN_B : BN_A + 8192);
@@ -146,10 +157,6 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
     // fragments wq and, for wq < 2, wq + 4
     const bool two = wq < 2;
     bn_f32x16 acc1[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
     // this thread's two 16-B pieces of a quarter's [128 px][64 ch] output image: e = tid + 512 it -> pixel e >> 3, chunk e & 7
     bn_u32x4 rres[4][2];
     int res_lds[2];   // IDENT: where that piece of the residual sits in an x chunk (halo row of the centre pixel, swizzled chunk)
@@ -161,8 +168,18 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
     }
     dma_chunk_a(0, 0);
     if (a.nch > 1) dma_chunk_a(1, 1);
+    if constexpr (MODE == 2) {   // Wd (256 x 64) -> regions B + C (buffer b is idle: one chunk only): 32 pieces, 4 per wave
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (wave + 8 * j) * 8 + srow;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wd, (lds_void *)(smem + BN_B + (wave + 8 * j) * 1024), 16,
+                                                     (row * 64 + ((lane & 7) ^ ((row >> 1) & 7)) * 8) * 2, 0, 0, 0);
+        }
+    }
     float *bias12 = reinterpret_cast<float *>(smem + BN_D);
     if (tid < 128) bias12[tid] = b12_early;   // the load is older than every DMA: waiting for it drains nothing
+    if (MODE == 2 && tid < 256) bias12[128 + tid] = bd_early;
+    unsigned resd[4][8];   // MODE 2: bf16(Wd . x + bd) of this wave's four (cout fragment, pixel fragment) tiles, accumulator layout
     for (int kt = 0; kt < a.nch; ++kt) {
         // this wave's share of chunk kt has landed; the 4 younger DMAs (chunk kt + 1, or the W2 taps requested below) stay in flight
         if (kt + 1 < a.nch || a.nch >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -170,6 +187,37 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
         BN_BAR_RAW();
         if (kt == 0) BN_STAMP(1);
         const char *Wt = smem + ((kt & 1) ? BN_C : BN_A), *Xt = smem + ((kt & 1) ? BN_B : BN_A + 8192);
+        if constexpr (MODE == 2) {   // the downsample conv on the centre pixels (kt == 0 is the only chunk)
+            const int pc_ = 32 * wq + lr;
+            const int rc = ((pc_ >> 4) + 1) * BN_HW + (pc_ & 15) + 1;   // halo row of this lane's centre pixel
+            bn_bf16x8 fx[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fx[kk] = *reinterpret_cast<const bn_bf16x8 *>(Xt + bn_swz(rc, 2 * kk + lh));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bn_f32x16 accd;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) accd[e] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const bn_bf16x8 fa = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_B + bn_swz(64 * q + 32 * wc + lr, 2 * kk + lh));
+                    accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fx[kk], accd, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(bias12 + 128 + 64 * q + 32 * wc + 8 * g + 4 * lh);
+                    resd[q][2 * g + 0] = bn_pk_bf16(accd[4 * g + 0] + bv.x, accd[4 * g + 1] + bv.y);
+                    resd[q][2 * g + 1] = bn_pk_bf16(accd[4 * g + 2] + bv.z, accd[4 * g + 3] + bv.w);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keeps hipcc from hoisting all four quarters' fragment reads (register budget)
+            }
+        }
+        if (kt == 0) {   // (zeroed here, behind the MODE 2 block: its accumulators and these are then never live together)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const bn_bf16x8 fa = *reinterpret_cast<const bn_bf16x8 *>(Wt + bn_swz(32 * wc + lr, 2 * kk + lh));
@@ -180,7 +228,7 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
                 acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb1, acc1[1], 0, 0, 0);
             }
         }
-        if constexpr (IDENT) {
+        if constexpr (MODE == 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (q == kt) {
@@ -234,16 +282,20 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
     for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
     const int pB = 32 * wq + lr;
     const int r0 = (pB >> 4) * BN_HW + (pB & 15);   // halo row of this lane's pixel for tap (0, 0)
+    // a tap's eight fragments are requested together, then its four MFMAs run: one LDS round trip per tap (the other three waves of
+    // the SIMD fill it); a second register set for cross-tap prefetch does not fit the 128-register budget of 4 waves per SIMD
     auto tap_mfma = [&](int t, const char *Wt) {
         const char *T1 = smem + BN_B;
         const int r = r0 + (t / 3) * BN_HW + (t % 3);
         const int sw = (r >> 1) & 7;
+        bn_bf16x8 tfa[4], tfb[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const bn_bf16x8 fb = *reinterpret_cast<const bn_bf16x8 *>(T1 + r * BN_ROWB + (((2 * kk + lh) ^ sw) << 4));
-            const bn_bf16x8 fa = *reinterpret_cast<const bn_bf16x8 *>(Wt + bn_swz(32 * wc + lr, 2 * kk + lh));
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc2, 0, 0, 0);
+            tfb[kk] = *reinterpret_cast<const bn_bf16x8 *>(T1 + r * BN_ROWB + (((2 * kk + lh) ^ sw) << 4));
+            tfa[kk] = *reinterpret_cast<const bn_bf16x8 *>(Wt + bn_swz(32 * wc + lr, 2 * kk + lh));
         }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfa[kk], tfb[kk], acc2, 0, 0, 0);
     };
 #pragma unroll
     for (int t = 0; t < 4; ++t) tap_mfma(t, smem + BN_A + t * 8192);
@@ -295,7 +347,7 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
     // ---- phase C: y = relu(W3 . T2 + b3 + residual), 64 output channels at a time = 2 cout x 4 pixel fragments per quarter
     const float *bias3 = reinterpret_cast<const float *>(smem + BN_C);
     char *E = smem + BN_B;
-    if constexpr (!IDENT) {   // a separate residual tensor: all 8 pieces requested now, behind every DMA of the tile
+    if constexpr (MODE == 1) {   // a separate residual tensor: all 8 pieces requested now, behind every DMA of the tile
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -304,6 +356,14 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
                 if (g_off[it] >= 0) rres[q][it] = __builtin_nontemporal_load(reinterpret_cast<const bn_u32x4 *>(a.res + g_off[it] + 64 * q));
             }
     }
+    // the pixel operand (T2 fragments) is the same for all four quarters: read once; the weight fragments of quarter q + 1 are
+    // requested before quarter q's epilogue (W3 is read-only in this phase: no hazard with the image barriers)
+    bn_bf16x8 fbc[4], fac[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        fbc[kk] = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_D + bn_swz(32 * wq + lr, 2 * kk + lh));
+        fac[0][kk] = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_A + bn_swz(32 * wc + lr, 2 * kk + lh));
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         bn_f32x16 acc3;
@@ -311,9 +371,8 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
         for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const bn_bf16x8 fa = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_A + bn_swz(64 * q + 32 * wc + lr, 2 * kk + lh));
-            const bn_bf16x8 fb = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_D + bn_swz(32 * wq + lr, 2 * kk + lh));
-            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc3, 0, 0, 0);
+            if (q + 1 < 4) fac[(q + 1) & 1][kk] = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_A + bn_swz(64 * (q + 1) + 32 * wc + lr, 2 * kk + lh));
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fac[q & 1][kk], fbc[kk], acc3, 0, 0, 0);
         }
         if (q == 1) BN_STAMP(13);
 #pragma unroll
@@ -323,6 +382,15 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
             uint2 pk;
             pk.x = bn_pk_bf16(acc3[4 * g + 0] + bv.x, acc3[4 * g + 1] + bv.y);
             pk.y = bn_pk_bf16(acc3[4 * g + 2] + bv.z, acc3[4 * g + 3] + bv.w);
+            if constexpr (MODE == 2) {   // + bf16(Wd . x + bd), ReLU: the final value goes into the image
+                const unsigned r0_ = resd[q][2 * g], r1_ = resd[q][2 * g + 1];
+                const bn_f32x2 s0 = (bn_f32x2){__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u)} +
+                                    (bn_f32x2){__uint_as_float(r0_ << 16), __uint_as_float(r0_ & 0xffff0000u)};
+                const bn_f32x2 s1 = (bn_f32x2){__uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)} +
+                                    (bn_f32x2){__uint_as_float(r1_ << 16), __uint_as_float(r1_ & 0xffff0000u)};
+                pk.x = bn_pk_relu(bn_pk_bf16(s0.x, s0.y));
+                pk.y = bn_pk_relu(bn_pk_bf16(s1.x, s1.y));
+            }
             *reinterpret_cast<uint2 *>(E + pB * BN_ES + c_local * 2) = pk;
         }
         BN_BAR_RAW();   // raw barriers in this loop: __syncthreads() would wait for the previous quarter's stores to COMPLETE (vmcnt 0)
@@ -332,12 +400,14 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
             if (g_off[it] < 0) continue;
             const int e = tid + 512 * it;
             bn_u32x4 v = *reinterpret_cast<const bn_u32x4 *>(E + (e >> 3) * BN_ES + (e & 7) * 16);
-            const bn_u32x4 rv = rres[q][it];
+            if constexpr (MODE != 2) {
+                const bn_u32x4 rv = rres[q][it];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bn_f32x2 sum = (bn_f32x2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)} +
-                                     (bn_f32x2){__uint_as_float(rv[k] << 16), __uint_as_float(rv[k] & 0xffff0000u)};
-                v[k] = bn_pk_relu(bn_pk_bf16(sum.x, sum.y));
+                for (int k = 0; k < 4; ++k) {
+                    const bn_f32x2 sum = (bn_f32x2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)} +
+                                         (bn_f32x2){__uint_as_float(rv[k] << 16), __uint_as_float(rv[k] & 0xffff0000u)};
+                    v[k] = bn_pk_relu(bn_pk_bf16(sum.x, sum.y));
+                }
             }
             __builtin_nontemporal_store(v, reinterpret_cast<bn_u32x4 *>(a.y + g_off[it] + 64 * q));
         }
@@ -364,27 +434,33 @@ extern "C" int md_diag_set_bn_stamp_buffer(void *p) { g_bn_stamp_buf = (unsigned
 #endif
 
 // in : x[N,H,W,Cin] bf16 (Cin = 64 or 256), w1[64,Cin] bf16, b12[128] f32 (= b1 | b2), w2[64,576] bf16 (K = tap*64 + ci),
-//      w3[256,64] bf16, b3[256] f32, residual[N,H,W,256] bf16 or NULL (= x, needs Cin == 256)
+//      w3[256,64] bf16, b3[256] f32, residual[N,H,W,256] bf16 | NULL, wd[256,64] bf16 | NULL, bd[256] f32 | NULL
 // out: y[N,H,W,256] bf16
+// residual source: wd given (Cin == 64, residual NULL) -> the downsample conv wd . x + bd computed in the launch; residual given ->
+// that tensor; neither (Cin == 256) -> x itself.
 extern "C" int md_bottleneck(MD_AOT_ARGS) {
-    if (nparam != 8) return MD_ERR_NPARAM;
+    if (nparam != 10) return MD_ERR_NPARAM;
     if (!params || !ndims || !shapes) return MD_ERR_ARG;
-    for (int i : {0, 1, 3, 4, 7})
+    for (int i : {0, 1, 3, 4, 9})
         if (!dtype_is(dtypes, i, "bfloat16")) return MD_ERR_ARG;
     for (int i : {2, 5})
         if (!dtype_is(dtypes, i, "float32")) return MD_ERR_ARG;
     if (params[6] && !dtype_is(dtypes, 6, "bfloat16")) return MD_ERR_ARG;
-    if (ndims[0] != 4 || ndims[7] != 4 || ndims[1] != 2 || ndims[3] != 2 || ndims[4] != 2) return MD_ERR_ARG;
+    if (ndims[0] != 4 || ndims[9] != 4 || ndims[1] != 2 || ndims[3] != 2 || ndims[4] != 2) return MD_ERR_ARG;
     const int64_t N = shapes[0][0], H = shapes[0][1], W = shapes[0][2], Cin = shapes[0][3];
     if ((Cin != 64 && Cin != 256) || shapes[1][0] != 64 || shapes[1][1] != Cin || shapes[3][0] != 64 || shapes[3][1] != 576 ||
         shapes[4][0] != 256 || shapes[4][1] != 64 || numel(ndims, shapes, 2) != 128 || numel(ndims, shapes, 5) < 256)
         return MD_ERR_ARG;
-    if (shapes[7][0] != N || shapes[7][1] != H || shapes[7][2] != W || shapes[7][3] != 256) return MD_ERR_ARG;
-    if (params[6]) {
+    if (shapes[9][0] != N || shapes[9][1] != H || shapes[9][2] != W || shapes[9][3] != 256) return MD_ERR_ARG;
+    if (params[7]) {   // fused downsample conv
+        if (params[6] || !params[8] || Cin != 64 || !dtype_is(dtypes, 7, "bfloat16") || !dtype_is(dtypes, 8, "float32") || ndims[7] != 2 ||
+            shapes[7][0] != 256 || shapes[7][1] != 64 || numel(ndims, shapes, 8) < 256)
+            return MD_ERR_ARG;
+    } else if (params[6]) {
         if (ndims[6] != 4 || numel(ndims, shapes, 6) != N * H * W * 256) return MD_ERR_ARG;
     } else if (Cin != 256) return MD_ERR_ARG;
     if (N * H * W == 0) return MD_OK;
-    for (int i : {0, 1, 2, 3, 4, 5, 7})
+    for (int i : {0, 1, 2, 3, 4, 5, 9})
         if (!params[i]) return MD_ERR_ARG;
     if (H > 32000 || W > 32000) return MD_ERR_SIZE;
     const long long x_img = H * W * Cin * 2;
@@ -392,7 +468,7 @@ extern "C" int md_bottleneck(MD_AOT_ARGS) {
     // 32-bit DMA offsets: run the batch as image chunks whose x tensor stays below 2 GiB (as md_conv2d does)
     const long long per = 0x7fff0000LL / x_img < N ? 0x7fff0000LL / x_img : N;
     const int tiles_x = (int)((W + BN_TW - 1) / BN_TW), tiles_y = (int)((H + BN_TH - 1) / BN_TH);
-    auto k = params[6] ? bottleneck64_kernel<false> : bottleneck64_kernel<true>;
+    auto k = params[7] ? bottleneck64_kernel<2> : (params[6] ? bottleneck64_kernel<1> : bottleneck64_kernel<0>);
     if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, BN_LDS) != hipSuccess) return MD_ERR_HIP;
     for (long long n0 = 0; n0 < N; n0 += per) {
         const long long nn = N - n0 < per ? N - n0 : per;
@@ -401,8 +477,9 @@ extern "C" int md_bottleneck(MD_AOT_ARGS) {
         a.w1 = (const uint16_t *)params[1]; a.b1 = (const float *)params[2];
         a.w2 = (const uint16_t *)params[3];
         a.w3 = (const uint16_t *)params[4]; a.b3 = (const float *)params[5];
-        a.res = (params[6] ? (const uint16_t *)params[6] : (const uint16_t *)params[0]) + n0 * H * W * 256;
-        a.y = (uint16_t *)params[7] + n0 * H * W * 256;
+        a.res = params[7] ? nullptr : (params[6] ? (const uint16_t *)params[6] : (const uint16_t *)params[0]) + n0 * H * W * 256;
+        a.wd = (const uint16_t *)params[7]; a.bd = (const float *)params[8];
+        a.y = (uint16_t *)params[9] + n0 * H * W * 256;
         a.N = (int)nn; a.H = (int)H; a.W = (int)W; a.Cin = (int)Cin; a.nch = (int)(Cin / 64);
         a.tiles_x = tiles_x; a.tiles_y = tiles_y;
         const long long n_tiles = nn * tiles_x * tiles_y;

@@ -121,10 +121,13 @@ class Bottleneck:
     def __call__(self, x):
         if FUSE_BLOCKS:
             if self._fused is False:   # packed on first use (the convs are packed by ResNet.to)
-                self._fused = nn_ops.pack_bottleneck(self.conv1.packed, self.conv2.packed, self.conv3.packed)
+                self._fused = nn_ops.pack_bottleneck(self.conv1.packed, self.conv2.packed, self.conv3.packed,
+                                                     self.downsample.packed if self.downsample is not None else None)
             if self._fused is not None:
-                # one launch for the whole block (md_bottleneck): x is read once, the 64-channel intermediates stay in LDS
-                return nn_ops.bottleneck(x, self._fused, residual=self.downsample(x) if self.downsample is not None else None)
+                # one launch for the whole block (md_bottleneck): x is read once, the 64-channel intermediates stay in LDS, and the
+                # first block's 1x1 downsample conv is computed from the same x tile
+                res = self.downsample(x) if (self.downsample is not None and self._fused.wd is None) else None
+                return nn_ops.bottleneck(x, self._fused, residual=res)
         residual = self.downsample(x) if self.downsample is not None else x
         return self.conv3(self.conv2(self.conv1(x)), residual=residual)
 

@@ -139,41 +139,53 @@ def conv2d_head(x, pc, pc2, variant=None):
 
 
 class PackedBottleneck:
-    """The three packed convs of a stride-1 bottleneck block with 64 mid channels, as md_bottleneck consumes them."""
+    """The three packed convs of a stride-1 bottleneck block with 64 mid channels (+ its 1x1 downsample conv), as md_bottleneck
+    consumes them."""
 
-    def __init__(self, pc1, pc2, pc3):
+    def __init__(self, pc1, pc2, pc3, pd=None):
         self.cin, self.cout = pc1.cin, pc3.cout
         self.w1, self.w2, self.w3 = pc1.w, pc2.w, pc3.w
         self.b12 = torch.cat([pc1.bias[:64], pc2.bias[:64]]).contiguous()
         self.b3 = pc3.bias
-        self.macs_per_pixel = pc1.cin_real * 64 + 9 * 64 * 64 + 64 * 256
+        self.wd, self.bd = (pd.w, pd.bias) if pd is not None else (None, None)
+        self.macs_per_pixel = pc1.cin_real * 64 + 9 * 64 * 64 + 64 * 256 + (pd.cin_real * 256 if pd is not None else 0)
 
     def flops_bytes(self, n, h, w, with_residual_tensor=False):
         """algorithmic flops and bytes of the block as ONE op: x read once, y written once (+ a separate residual tensor)"""
         px = n * h * w
-        byts = 2.0 * (px * (self.cin + 256 + (256 if with_residual_tensor else 0)) + self.w1.numel() + self.w2.numel() + self.w3.numel())
+        wts = self.w1.numel() + self.w2.numel() + self.w3.numel() + (self.wd.numel() if self.wd is not None else 0)
+        byts = 2.0 * (px * (self.cin + 256 + (256 if with_residual_tensor else 0)) + wts)
         return 2.0 * px * self.macs_per_pixel, byts
 
 
-def pack_bottleneck(pc1, pc2, pc3):
-    """-> PackedBottleneck if (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + residual) is the shape md_bottleneck fuses, else None."""
+def pack_bottleneck(pc1, pc2, pc3, pd=None):
+    """-> PackedBottleneck if (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + residual) is the shape md_bottleneck fuses, else None.
+    pd: the block's downsample conv; it is fused too when it is a plain 1x1 / stride 1 conv on 64 input channels (then
+    bottleneck() needs no residual argument), otherwise the caller runs it and passes its output as the residual."""
     ok = (pc1.kh == 1 and pc1.stride == 1 and pc1.pad == 0 and pc1.relu == 1 and pc1.cout == 64 and pc1.cin in (64, 256) and
           tuple(pc1.w.shape) == (64, pc1.cin) and
           pc2.kh == 3 and pc2.kw == 3 and pc2.stride == 1 and pc2.pad == 1 and pc2.relu == 1 and pc2.cin == 64 and pc2.cout == 64 and
           tuple(pc2.w.shape) == (64, 576) and
           pc3.kh == 1 and pc3.stride == 1 and pc3.pad == 0 and pc3.relu == 1 and pc3.cin == 64 and pc3.cout == 256 and
           tuple(pc3.w.shape) == (256, 64))
-    return PackedBottleneck(pc1, pc2, pc3) if ok else None
+    if not ok:
+        return None
+    fuse_ds = (pd is not None and pd.kh == 1 and pd.stride == 1 and pd.pad == 0 and pd.relu == 0 and pd.cin == 64 and pc1.cin == 64 and
+               pd.cout == 256 and tuple(pd.w.shape) == (256, 64))
+    return PackedBottleneck(pc1, pc2, pc3, pd if fuse_ds else None)
 
 
 def bottleneck(x, blk, residual=None, out=None):
-    """y = relu(conv3(relu(conv2(relu(conv1(x))))) + residual) in one md_bottleneck launch; residual None = x (identity block)."""
+    """y = relu(conv3(relu(conv2(relu(conv1(x))))) + residual) in one md_bottleneck launch.  residual None: the block's own
+    downsample conv if it was packed into blk (computed in the launch), else x itself (identity block)."""
     n, h, w, c = x.shape
     if c != blk.cin:
         raise _lib.MindDetHipError(f"bottleneck: input has {c} channels, block packed for {blk.cin}")
     if out is None:
         out = torch.empty((n, h, w, 256), dtype=torch.bfloat16, device=x.device)
-    _lib.call("md_bottleneck", [x, blk.w1, blk.b12, blk.w2, blk.w3, blk.b3, residual, out])
+    fused_ds = blk.wd is not None and residual is None
+    _lib.call("md_bottleneck", [x, blk.w1, blk.b12, blk.w2, blk.w3, blk.b3, residual, blk.wd if fused_ds else None,
+                                blk.bd if fused_ds else None, out])
     return out
 
 

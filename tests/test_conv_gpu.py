@@ -362,15 +362,18 @@ def test_fused_bottleneck_equals_three_launches(cfg):
 
     name, N, H, W, Cin, ds = cfg
     (pc1, pc2, pc3), pd, g = _bottleneck_modules(Cin, len(name) * 13 + H, ds)
-    blk = nn_ops.pack_bottleneck(pc1, pc2, pc3)
-    assert blk is not None
+    blk = nn_ops.pack_bottleneck(pc1, pc2, pc3, pd)
+    assert blk is not None and (blk.wd is not None) == ds
     x = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16).to(DEV)
     res = nn_ops.conv2d(x, pd) if ds else x
     ref = nn_ops.conv2d(nn_ops.conv2d(nn_ops.conv2d(x, pc1), pc2), pc3, residual=res)
-    y = nn_ops.bottleneck(x, blk, residual=res if ds else None)
+    y = nn_ops.bottleneck(x, blk)                       # identity residual, or the downsample conv computed in the launch
     assert _lib.lib().md_conv2d_last_kernel() == 7
     torch.cuda.synchronize()
     assert torch.equal(y, ref), (y.float() - ref.float()).abs().max().item()
+    if ds:   # the same block with the downsample conv run by the caller (residual tensor form)
+        y1 = nn_ops.bottleneck(x, nn_ops.pack_bottleneck(pc1, pc2, pc3), residual=res)
+        assert torch.equal(y1, ref)
     # fp32 torch on the bf16-rounded operands (bf16 rounding of the two intermediates reproduced)
     xf = x.float().cpu().permute(0, 3, 1, 2)
 
@@ -402,6 +405,12 @@ def test_fused_bottleneck_argument_checks_and_determinism():
         nn_ops.bottleneck(x, blk, out=torch.zeros((2, 16, 32, 128), dtype=torch.bfloat16, device=DEV))
     with pytest.raises(_lib.MindDetHipError, match="rc=2"):      # residual shape
         nn_ops.bottleneck(x, blk, residual=torch.zeros((2, 16, 32, 64), dtype=torch.bfloat16, device=DEV))
+    with pytest.raises(_lib.MindDetHipError, match="rc=2"):      # a fused downsample conv and a residual tensor exclude each other
+        (p1, p2, p3), pd, _ = _bottleneck_modules(64, 7, True)
+        b64 = nn_ops.pack_bottleneck(p1, p2, p3, pd)
+        x64 = torch.zeros((1, 8, 16, 64), dtype=torch.bfloat16, device=DEV)
+        _lib.call("md_bottleneck", [x64, b64.w1, b64.b12, b64.w2, b64.w3, b64.b3, torch.zeros((1, 8, 16, 256), dtype=torch.bfloat16, device=DEV),
+                                    b64.wd, b64.bd, torch.zeros((1, 8, 16, 256), dtype=torch.bfloat16, device=DEV)])
     # blocks md_bottleneck does not take are not packed: the graph keeps the three-launch path for them
     p128 = nn_ops.pack_conv(torch.randn((128, 512, 1, 1)) * 0.05, relu=True).to(DEV)
     assert nn_ops.pack_bottleneck(p128, pc2, pc3) is None

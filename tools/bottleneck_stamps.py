@@ -20,9 +20,10 @@ g = torch.Generator().manual_seed(0)
 pc1 = nn_ops.pack_conv(torch.randn((64, Cin, 1, 1), generator=g) * (2.0 / Cin) ** 0.5, bias=torch.zeros(64), relu=True).to(dev)
 pc2 = nn_ops.pack_conv(torch.randn((64, 64, 3, 3), generator=g) * (2.0 / 576) ** 0.5, bias=torch.zeros(64), stride=1, pad=1, relu=True).to(dev)
 pc3 = nn_ops.pack_conv(torch.randn((256, 64, 1, 1), generator=g) * (2.0 / 64) ** 0.5, bias=torch.zeros(256), relu=True).to(dev)
-blk = nn_ops.pack_bottleneck(pc1, pc2, pc3)
+pd = nn_ops.pack_conv(torch.randn((256, Cin, 1, 1), generator=g) * 0.1, bias=torch.zeros(256), relu=False).to(dev) if Cin == 64 else None
+blk = nn_ops.pack_bottleneck(pc1, pc2, pc3, pd)
 x = torch.relu(torch.randn((B, H, W, Cin), generator=torch.Generator(device=dev).manual_seed(1), device=dev)).to(torch.bfloat16)
-res = None if Cin == 256 else torch.zeros((B, H, W, 256), dtype=torch.bfloat16, device=dev)
+res = None
 for _ in range(5):
     nn_ops.bottleneck(x, blk, residual=res)
 torch.cuda.synchronize()
