@@ -1174,6 +1174,19 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     }
 }
 
+// The MFMA shape of the ping-pong kernel per layer (r02, tools/pp_mf_ab.py, batch 60, same box, bit-identical results): the chip
+// holds a higher clock on v_mfma_f32_16x16x32_bf16 in the long K = 2304 loops of the big 3x3 layers (200x336: +2.5 %, 100x168:
+// +1.6 %, 50x84: +0.9 %) and a lower one on the short-K / small-grid layers (1x1 1024->256: -7 %, 3x3 512->512 at 25x42: -3 %).
+static bool pingpong_wants_16x16(const ConvArgs &a) { return a.kh == 3 && a.kw == 3 && a.Kpad >= 2304 && a.M >= 400000; }
+
+template <int MF>
+static int launch_conv_pingpong_head_mf(ConvArgs &a, hipStream_t s, long long blocks, int lds) {
+    auto k = conv_pingpong_kernel<0, MF, 0, true>;
+    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
+}
+
 static int launch_conv_pingpong_head(ConvArgs &a, hipStream_t s) {
     g_last_kernel = MD_CONV_KERNEL_PINGPONG;
     a.n_ctiles = 1;
@@ -1182,10 +1195,7 @@ static int launch_conv_pingpong_head(ConvArgs &a, hipStream_t s) {
     const long long blocks = (long long)a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
     const int lds = 256 * (256 * 2 + 16) + 256 * 4 + 16 * 256 * 2;  // epilogue image + bias + head weights
-    auto k = conv_pingpong_kernel<0, 0, false, true>;
-    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, s, a);
-    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
+    return pingpong_wants_16x16(a) ? launch_conv_pingpong_head_mf<1>(a, s, blocks, lds) : launch_conv_pingpong_head_mf<0>(a, s, blocks, lds);
 }
 
 template <int ABL = 0, int MF = 0>
@@ -1197,7 +1207,7 @@ static int launch_conv_pingpong(ConvArgs &a, hipStream_t s) {
     const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
     const int lds = 256 * (256 * 2 + 16) + 256 * 4;  // 136,192 B: the epilogue image (>= the 128 KiB of staging buffers) + bias
-    constexpr bool HAS_PLAIN = (ABL == 0 || ABL == 4) && MF == 0;
+    constexpr bool HAS_PLAIN = ABL == 0 || (ABL == 4 && MF == 0);
     const bool cat_only = a.adv && a.os == 1 && !a.oy && !a.ox && a.Ho == a.Hf && a.Wo == a.Wf;
     const bool plain = HAS_PLAIN && (!a.adv || cat_only) && !a.res_up;
     auto k = conv_pingpong_kernel<ABL, MF, 1>;
@@ -1402,7 +1412,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
                               cout_pad % 64 == 0 && !a.res_up &&
                               a.Ho == a.H && a.Wo == a.W && (!pp_ok || pp_ragged) && halo_fits;
     if (halo64_first) return launch_conv3x3_halo<64, true>(a, s);
-    if (variant == 0 && pp_ok) return launch_conv_pingpong<0>(a, s);
+    if (variant == 0 && pp_ok) return pingpong_wants_16x16(a) ? launch_conv_pingpong<0, 1>(a, s) : launch_conv_pingpong<0>(a, s);
     if (halo_ok && !a.res_up && variant == 11) return launch_conv3x3_halo<128, false>(a, s);  // superseded by the paths around it
     // 64-cout tiles of the halo kernel at four workgroups per CU (variant 27; auto for Cout <= 64)
     // (a channel-concat output is fine: the kernel stores with the output tensor's channel stride; sub-pixel addressing is not)
