@@ -17,7 +17,7 @@ The JSON line also carries
   roofline     -- the DOMINANT conv kernel by time (md_conv2d_last_kernel attributes every launch; each is bracketed by
                   HIP events on the launch stream) against the roofline that binds its launches in aggregate
                   (algorithmic flops / 2.5 PFLOP/s dense bf16 or algorithmic bytes / 8 TB/s), its PMC traffic from
-                  profiles/r01_conv_traffic.json, and under "all_conv" the same per kernel and for the whole conv/FC set
+                  profiles/r02_conv_traffic.json, and under "all_conv" the same per kernel and for the whole conv/FC set
                   (incl. frac_of_layerwise_roofline = sum of per-launch max(flops/peak, bytes/peak) / measured time).
   cpu_baseline -- the oracle's plain fp32 torch-CPU restatement of the same graph (oracle/nets.py) timed on this
                   host's cores on a bounded sample (rank 0, N=1 only).
@@ -60,6 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--dump-convs", default=None, help="write per-launch conv timings (json) to this path")
     ap.add_argument("--spawn", action="store_true",
                     help="start the --gpus ranks from this process even for N = 1 (the RCCL path with one rank)")
+    ap.add_argument("--no-from-uint8", action="store_true", help="skip the extra from-uint8 pass (from_uint8 in the line)")
     ap.add_argument("--no-zero-operands", action="store_true",
                     help="skip the zero-operand replay of the dominant kernel (roofline.zero_operands)")
     return ap.parse_args(argv)
@@ -256,6 +257,8 @@ def main(argv=None):
     from minddet_amd.data import synthetic_images
     from minddet_amd.shard import gather_detections_async
 
+    if not os.path.exists(args.config) and os.path.exists(os.path.join(ROOT, args.config)):
+        args.config = os.path.join(ROOT, args.config)   # a repo-relative path from another working directory (rocprofv3 runs from /tmp)
     cfg = Config.fromfile(args.config)
     model = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(dev)
     H, W = cfg.data.input_hw
@@ -405,7 +408,7 @@ def main(argv=None):
 
     # the end-to-end figure from a resident uint8 batch (md_image_preprocess inside the step), next to the resident-layout one
     from_u8 = None
-    if not args.from_uint8 and not args.graph and rank == 0 and not use_dist and hasattr(nn_ops, "image_preprocess"):
+    if not args.from_uint8 and not args.no_from_uint8 and not args.graph and rank == 0 and not use_dist and hasattr(nn_ops, "image_preprocess"):
         u8, mat = make_u8()
         pre2 = lambda: nn_ops.image_preprocess(u8, mat, MEAN, STD, (H, W), stem_layout=images.shape[3] == 4)  # noqa: E731
         step2, finish2 = make_step(lambda xx: model.forward(xx), images, False, None, pre2)
@@ -446,8 +449,8 @@ def main(argv=None):
         # layer-wise roofline: each launch is bounded by max(flops / MFMA peak, algorithmic bytes / HBM peak)
         t_roof_ms = sum(max(r[2] / (PEAK_BF16_TFLOPS * 1e12), r[6] / PEAK_HBM_BPS) for r in all_recs) * 1e3
         traffic = all_traffic = None
-        tp = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
-        PMC_PREFIX = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<256, 2, 2, 2, 2, 2,"}  # all instantiations of the kernel
+        tp = os.path.join(ROOT, "profiles", "r02_conv_traffic.json")
+        PMC_PREFIX = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<256, 2, 2, 2, 2, 2,", 7: "bottleneck64_kernel"}  # all instantiations of the kernel
         if os.path.exists(tp):  # PMC passes are separate rocprofv3 runs (tools/pmc_traffic.py); same config only
             tj = json.load(open(tp))
             if tj.get("batch_per_gpu") == B and type(model).__name__ == "FasterRCNN":
@@ -460,7 +463,7 @@ def main(argv=None):
                     "bracketed": "HIP events around this kernel's launches in the timed region" + (
                         "; all_conv: every launch of the last warmup step" if survey else "; all_conv: every launch of the timed region"),
                     "achieved": round(ach, 2), "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "traffic_unit": "MB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_conv_traffic.json)",
+                    "traffic": traffic, "traffic_unit": "MB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_conv_traffic.json)",
                     "achieved_tflops": round(d_fl / (d_ms * 1e-3) / 1e12, 2),
                     "algorithmic_mb_per_launch": round(d_by / d_n / 1e6, 2),
                     "algorithmic_gflop_per_launch": round(d_fl / d_n / 1e9, 1),
@@ -525,13 +528,20 @@ def main(argv=None):
             del x_r, x_z, y_buf
 
     if args.dump_convs and rank == 0 and records:
+        # per-layer table: measured time against the layer's own roofline max(flops / MFMA peak, algorithmic bytes / HBM peak)
         per = {}
-        for e0, e1, fl, xs, cout, k, _b, _kid, *_pcs in records:
-            key = f"{xs}->{cout} k{k}"
-            d = per.setdefault(key, [0.0, 0.0, 0])
-            d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += 1
-        rows = [{"layer": k_, "ms_per_step": v[0] / args.steps, "tflops": v[1] / (v[0] * 1e-3) / 1e12 if v[0] > 0 else 0,
-                 "launches_per_step": v[2] // args.steps} for k_, v in per.items()]
+        for e0, e1, fl, xs, cout, k, byts, kid, *_pcs in records:
+            key = f"{xs}->{cout} k{k}" + (" [block]" if kid == 7 else "")
+            d = per.setdefault(key, [0.0, 0.0, 0, 0.0, kid])
+            d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += 1; d[3] += byts
+        rows = []
+        for k_, v in per.items():
+            t_roof = max(v[1] / (PEAK_BF16_TFLOPS * 1e12), v[3] / PEAK_HBM_BPS) * 1e3
+            rows.append({"layer": k_, "kernel": KNAMES.get(v[4], str(v[4])), "launches_per_step": v[2] // args.steps,
+                         "ms_per_step": round(v[0] / args.steps, 4), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0,
+                         "algorithmic_tb_per_s": round(v[3] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else 0,
+                         "bound": "mfma" if v[1] / (PEAK_BF16_TFLOPS * 1e12) >= v[3] / PEAK_HBM_BPS else "hbm",
+                         "roofline_ms_per_step": round(t_roof / args.steps, 4), "frac_of_roofline": round(t_roof / v[0], 3) if v[0] > 0 else 0})
         rows.sort(key=lambda r: -r["ms_per_step"])
         with open(args.dump_convs, "w") as f:
             json.dump(rows, f, indent=1)
