@@ -151,13 +151,18 @@ __global__ __launch_bounds__(256) void nms_aligned_mask_kernel(const float *__re
                                                                 const int *__restrict__ count,
                                                                 const int *__restrict__ group_all, int n_max,
                                                                 float thr, float eps, int mode,
-                                                                unsigned long long *__restrict__ mask_all, int cb) {
+                                                                unsigned long long *__restrict__ mask_all, int cb,
+                                                                int cb_tri, int n_limit, const int *__restrict__ gate) {
+    // cb = words per mask row (row stride); the launch covers the upper triangle of the first cb_tri x cb_tri tiles and the first
+    // n_limit boxes of a list (the quota prefix pass of md_nms_aligned; cb_tri = cb, n_limit = n_max for a full pass); gate: the
+    // full pass behind a prefix pass runs only for the lists whose flag is set
     __shared__ float row_box[TILE * 4];
     __shared__ int row_grp[TILE];
     const int list = blockIdx.y;
-    const int n = count ? min(count[list], n_max) : n_max;
+    if (gate && gate[list] == 0) return;
+    const int n = min(count ? min(count[list], n_max) : n_max, n_limit);
     int rb, cbk;
-    tri_tile(blockIdx.x, cb, rb, cbk);
+    tri_tile(blockIdx.x, cb_tri, rb, cbk);
     if (rb * TILE >= n) return;  // block-uniform: nothing valid in this row block
     const float *boxes = boxes_all + (size_t)list * n_max * 4;
     const int *group = group_all ? group_all + (size_t)list * n_max : nullptr;
@@ -314,10 +319,16 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long 
                                                         const float *__restrict__ dead_area, int dead_stride,
                                                         int max_output, KeepT *__restrict__ keep_all,
                                                         int *__restrict__ num_all,
-                                                        unsigned char *__restrict__ keepmask_all) {
+                                                        unsigned char *__restrict__ keepmask_all, int n_limit = 0x7fffffff,
+                                                        const int *__restrict__ gate = nullptr,
+                                                        int *__restrict__ need_full = nullptr) {
+    // n_limit / gate / need_full: the quota prefix pass of md_nms_aligned (see there).  A prefix pass looks at the first n_limit
+    // boxes only and raises need_full[list] when they did not fill the quota although the list goes on.
     extern __shared__ unsigned long long remv[];  // cb words + 1 (kept word broadcast)
     const int list = blockIdx.x;
-    const int n = count ? min(count[list], n_max) : n_max;
+    if (gate && gate[list] == 0) return;
+    const int n_all = count ? min(count[list], n_max) : n_max;
+    const int n = min(n_all, n_limit);
     const unsigned long long *mask = mask_all + (size_t)list * n_max * cb;
     KeepT *keep = keep_all + (size_t)list * n_max;
     unsigned char *keepmask = keepmask_all ? keepmask_all + (size_t)list * n_max : nullptr;
@@ -368,14 +379,17 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long 
         // OR the kept rows' words into the removed-words of later column blocks:
         // lane = row of this block, one wave per column block, DPP/shuffle OR-reduction.
         const bool mine = (kept >> lane) & 1ull;
-        for (int j = blk + 1 + wave; j < cb; j += 4) {
+        for (int j = blk + 1 + wave; j < nb; j += 4) {   // (column blocks past the last valid box carry no bits)
             unsigned long long v = mine ? mask[(size_t)(base + lane) * cb + j] : 0ull;
             v = wave_or64(v);
             if (lane == 0) remv[j] |= v;
         }
         __syncthreads();
     }
-    if (tid == 0) num_all[list] = total;
+    if (tid == 0) {
+        num_all[list] = total;
+        if (need_full) need_full[list] = (max_output > 0 && total < max_output && n_all > n) ? 1 : 0;
+    }
 }
 
 // ------------------------------------------------------------------ IoU matrices
@@ -693,16 +707,43 @@ extern "C" int md_nms_aligned(MD_AOT_ARGS) {
     if (n == 0) return hipMemsetAsync(params[5], 0, sizeof(int) * B, s) == hipSuccess ? MD_OK : MD_ERR_HIP;
     if (!params[0]) return MD_ERR_ARG;
     const int cb = (int)((n + TILE - 1) / TILE);
+    const size_t mask_bytes = (size_t)B * n * cb * 8;
+    // Quota prefix pass.  With an output quota (max_output > 0) the scan stops at the quota-th kept box, and a box is suppressed by
+    // higher-ranked kept boxes only: the first P boxes decide among themselves, so when they already yield max_output survivors the
+    // P x P corner of the mask is all that was ever needed (YOLO: 4 096 candidates, quota 300 -> 190 tiles instead of 2 080 per
+    // image).  Pass 1 = mask corner + scan over the first P boxes; it raises a per-list flag when the quota was NOT filled although
+    // the list goes on, and pass 2 (full mask + full scan, gated by that flag on the device: no host synchronisation) redoes those
+    // lists from scratch.  Outputs are identical to the single full pass in every case.
+    const int64_t want = (int64_t)4 * at->max_output > 512 ? (int64_t)4 * at->max_output : 512;
+    const int P = (int)((want + TILE - 1) / TILE * TILE);
+    const bool two_level = at->max_output > 0 && n >= 2 * (int64_t)P;
+    const size_t flag_bytes = two_level ? align_up((size_t)B * 4, 256) : 0;
     Scratch ws;
-    int rc = ws.acquire((size_t)B * n * cb * 8, nparam, params, ndims, shapes, 6, s);
+    int rc = ws.acquire(mask_bytes + flag_bytes, nparam, params, ndims, shapes, 6, s);
+    bool tl = two_level;
+    if (rc == MD_ERR_SIZE && two_level) {   // a caller workspace sized for the mask only: single full pass
+        tl = false;
+        rc = ws.acquire(mask_bytes, nparam, params, ndims, shapes, 6, s);
+    }
     if (rc) return rc;
     unsigned long long *mask = (unsigned long long *)ws.ptr;
+    int *need_full = nullptr;
+    if (tl) {
+        need_full = (int *)((char *)ws.ptr + mask_bytes);   // (mask_bytes is a multiple of 8)
+        const int cbp = P / TILE;
+        hipLaunchKernelGGL(nms_aligned_mask_kernel, dim3(cbp * (cbp + 1) / 2, (unsigned)B), dim3(256), 0, s,
+                           (const float *)params[0], (const int *)params[1], (const int *)params[2], (int)n,
+                           at->iou_threshold, at->eps, at->mode, mask, cb, cbp, P, (const int *)nullptr);
+        hipLaunchKernelGGL((nms_scan_kernel<int>), dim3((unsigned)B), dim3(256), scan_lds(cb), s, mask,
+                           (const int *)params[1], (int)n, cb, (const float *)nullptr, 0, at->max_output, (int *)params[4],
+                           (int *)params[5], (unsigned char *)params[3], P, (const int *)nullptr, need_full);
+    }
     hipLaunchKernelGGL(nms_aligned_mask_kernel, dim3(cb * (cb + 1) / 2, (unsigned)B), dim3(256), 0, s,
                        (const float *)params[0], (const int *)params[1], (const int *)params[2], (int)n,
-                       at->iou_threshold, at->eps, at->mode, mask, cb);
+                       at->iou_threshold, at->eps, at->mode, mask, cb, cb, (int)n, (const int *)need_full);
     hipLaunchKernelGGL((nms_scan_kernel<int>), dim3((unsigned)B), dim3(256), scan_lds(cb), s, mask,
                        (const int *)params[1], (int)n, cb, (const float *)nullptr, 0, at->max_output, (int *)params[4],
-                       (int *)params[5], (unsigned char *)params[3]);
+                       (int *)params[5], (unsigned char *)params[3], 0x7fffffff, (const int *)need_full, (int *)nullptr);
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }

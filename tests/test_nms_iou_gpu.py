@@ -260,3 +260,41 @@ def test_quota_nms_batched_equals_list_by_list(cfg, mode):
         k1, i1, n1 = det_ops.nms_aligned(bt[l:l + 1], thr, mode=mode, count=ct[l:l + 1], group=gt[l:l + 1], max_output=quota)
         assert int(n1[0]) == int(num[l])
         assert torch.equal(k1[0], keep[l]) and torch.equal(i1[0, : int(n1[0])], kidx[l, : int(num[l])])
+
+
+@pytest.mark.parametrize("n,quota,ngroups", [(4096, 300, 80), (2048, 100, 80), (4096, 300, 1)])
+def test_quota_prefix_pass_equals_the_full_pass_and_the_oracle(n, quota, ngroups):
+    """md_nms_aligned's quota prefix pass (mask corner + scan over the first P boxes, full pass gated on the device for the lists that
+    did not fill the quota): per list identical to the oracle's greedy NMS cut at `quota` kept boxes -- lists that fill the quota
+    inside the prefix, lists that need the full pass (a long run of near-duplicates first) and short lists, in ONE batch; and identical
+    with a caller workspace that only holds the mask (single full pass)."""
+    from minddet_amd import det_ops
+
+    L = 6
+    rng = np.random.default_rng(n + quota + ngroups)
+    c = rng.uniform(0, 2000, (L, n, 2)).astype(np.float32)
+    wh = rng.uniform(10, 60, (L, n, 2)).astype(np.float32)
+    # lists 1 and 4: the first 3000 / 1800 boxes are near-copies of a few boxes per class -> the prefix collapses, the full pass must run
+    for l, m in ((1, min(3000, n - 200)), (4, min(1800, n - 200))):
+        c[l, :m] = np.array([500.0, 500.0], np.float32) + rng.normal(0, 1.0, (m, 2)).astype(np.float32)
+        wh[l, :m] = 50.0
+    boxes = np.concatenate([c - wh / 2, c + wh / 2], -1).astype(np.float32)
+    count = np.array([n, n, 700, n - 5, n, 2 * 64 + 3], np.int32)   # list 2 / 5: shorter than the prefix
+    group = rng.integers(0, ngroups, (L, n)).astype(np.int32)
+    bt, ct, gt = T(boxes), T(count), T(group)
+    keep, kidx, num = det_ops.nms_aligned(bt, 0.5, mode=det_ops.NMS_MODE_STRICT, count=ct, group=gt, max_output=quota)
+    ws = torch.empty((L * n * ((n + 63) // 64) * 8,), dtype=torch.uint8, device=DEV)
+    keep2, kidx2, num2 = det_ops.nms_aligned(bt, 0.5, mode=det_ops.NMS_MODE_STRICT, count=ct, group=gt, max_output=quota, workspace=ws)
+    assert torch.equal(keep, keep2) and torch.equal(kidx, kidx2) and torch.equal(num, num2)
+    needed_full = 0
+    for l in range(L):
+        m = int(count[l])
+        k_o = oracle.nms_aligned(boxes[l, :m], 0.5, 0.0, 2, groups=group[l, :m]).astype(bool)
+        kept = np.nonzero(k_o)[0][:quota]
+        assert int(num[l]) == len(kept)
+        np.testing.assert_array_equal(kidx.cpu().numpy()[l, :len(kept)], kept)
+        km = np.zeros(n, np.uint8); km[kept] = 1
+        np.testing.assert_array_equal(keep.cpu().numpy()[l], km)
+        P = (max(512, 4 * quota) + 63) // 64 * 64
+        needed_full += int(m > P and k_o[:P].sum() < quota)
+    assert needed_full >= 1   # the batch really exercises the gated full pass
