@@ -133,7 +133,7 @@ typedef struct md_conv2d_attrs {
                                     2 SiLU applied after bias, BEFORE the residual add (x + act(conv(x))) */
     int32_t variant;             /* 0 = auto (default: cost model in csrc/conv.hip).  Pins a kernel for A/B measurements:
                                     1 register-staged 128x128, 2 / 20 LDS-DMA 128x128 with two / one staging buffer,
-                                    5 128x128 on 16x16x32 MFMA, 11 / 27 halo-reuse kernel with 128- / 64-cout tiles,
+                                    11 / 27 halo-reuse kernel with 128- / 64-cout tiles,
                                     15 / 22 256x256 ping-pong kernel (32x32x16 / 16x16x32 MFMA); a variant whose
                                     preconditions do not hold falls back to the generic kernel.  17-19 and 25 (timing /
                                     stamp diagnostics that do NOT compute the convolution) exist only in the MD_DIAG build

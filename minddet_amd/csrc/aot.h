@@ -66,5 +66,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 // records which conv-family kernel the calling host thread launched last (md_conv2d_last_kernel); defined in conv.hip
 void md_note_conv_kernel(int id);
+// activation bytes above which a conv-family op slices the batch (md_conv2d_set_chunk_limit; 2 GiB - 64 KiB unless a test lowered it)
+long long md_chunk_limit();
 
 }  // namespace md

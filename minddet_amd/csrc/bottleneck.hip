@@ -465,8 +465,10 @@ extern "C" int md_bottleneck(MD_AOT_ARGS) {
     if (H > 32000 || W > 32000) return MD_ERR_SIZE;
     const long long x_img = H * W * Cin * 2;
     if (x_img >= 0x7fff0000LL) return MD_ERR_SIZE;
-    // 32-bit DMA offsets: run the batch as image chunks whose x tensor stays below 2 GiB (as md_conv2d does)
-    const long long per = 0x7fff0000LL / x_img < N ? 0x7fff0000LL / x_img : N;
+    // 32-bit DMA offsets: run the batch as image chunks whose x tensor stays below 2 GiB (as md_conv2d does; same limit, which
+    // tests lower through md_conv2d_set_chunk_limit)
+    const long long lim = md_chunk_limit() > x_img ? md_chunk_limit() : x_img;
+    const long long per = lim / x_img < N ? lim / x_img : N;
     const int tiles_x = (int)((W + BN_TW - 1) / BN_TW), tiles_y = (int)((H + BN_TH - 1) / BN_TH);
     auto k = params[7] ? bottleneck64_kernel<2> : (params[6] ? bottleneck64_kernel<1> : bottleneck64_kernel<0>);
     if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, BN_LDS) != hipSuccess) return MD_ERR_HIP;

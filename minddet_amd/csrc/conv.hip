@@ -141,14 +141,11 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 
 // DMA -> MFMA -> epilogue chains overlap each other), or two with the next tile's DMA issued before the MFMAs (variant 2).
 // Measured and removed in r01: 3-stage ring with counted vmcnt, producer/consumer waves, 4-stage
 // BK-32 ring, DMA issue interleaved with the MFMA clusters, 256x256 tile on this loop.
-// MF 0: v_mfma_f32_32x32x16_bf16 (FC x FP tiles of 32x32 per wave); MF 1: v_mfma_f32_16x16x32_bf16 (2FC x 2FP
-// tiles of 16x16, K 32 per instruction): same LDS traffic and cycles per flop, but the chip holds a higher
-// clock on the 16x16 shape under load (MI355X_MICROARCH.md, DVFS give-back item 7).
 // GEN 1: the general epilogue (sub-pixel output addressing, upsampled residual, any activation).  GEN 0 / 2: the plain
 // instantiations for ReLU-or-none / SiLU layers whose output is a whole tensor or a channel range of a concat buffer
 // (offset = m * Ctot + c_off + c): the division-heavy address code of the general epilogue is compiled out (it was 2/3 of the
 // kernel's instructions) and the activation is a compile-time choice.
-template <int NT, int WC, int WP, int FC, int FP, int MODE, int MF = 0, int GEN = 1>
+template <int NT, int WC, int WP, int FC, int FP, int MODE, int GEN = 1>
 __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr bool GLDS = MODE != 0;
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
@@ -296,24 +293,15 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         }
     };
 
-    f32x16 acc[MF ? 1 : FC][MF ? 1 : FP];
-    f32x4 acc4[MF ? 2 * FC : 1][MF ? 2 * FP : 1];
-    if constexpr (MF == 0) {
+    f32x16 acc[FC][FP];
 #pragma unroll
-        for (int i = 0; i < FC; ++i)
+    for (int i = 0; i < FC; ++i)
 #pragma unroll
-            for (int j = 0; j < FP; ++j)
+        for (int j = 0; j < FP; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2 * FC; ++i)
-#pragma unroll
-            for (int j = 0; j < 2 * FP; ++j) acc4[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int lr = lane & 31, lh = lane >> 5;
-    const int l16 = lane & 15, lq = lane >> 4;
     // fragment read addresses: the swizzle term is the same for every fragment row of a lane (rows differ by
     // multiples of 32), so 4 bases per operand (one per k-step) + immediates cover a whole tile
     int fa_off[BK / 16], fb_off[BK / 16];
@@ -322,34 +310,6 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         fa_off[kk] = swz(wc * FC * 32 + lr, kk * 2 + lh);
         fb_off[kk] = CT * ROWB + swz(wp * FP * 32 + lr, kk * 2 + lh);
     }
-    int ga_off[2], gb_off[2];  // MF 1: two K-32 steps per tile
-#pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
-        ga_off[k2] = swz(wc * FC * 32 + l16, k2 * 4 + lq);
-        gb_off[k2] = CT * ROWB + swz(wp * FP * 32 + l16, k2 * 4 + lq);
-    }
-    auto compute_tile16 = [&](int buf) {
-        const char *T = smem + buf * TILE_BYTES;
-        bf16x8 fa[2][2 * FC], fb[2][2 * FP];
-#pragma unroll
-        for (int i = 0; i < 2 * FC; ++i) fa[0][i] = *reinterpret_cast<const bf16x8 *>(T + ga_off[0] + i * 16 * ROWB);
-#pragma unroll
-        for (int j = 0; j < 2 * FP; ++j) fb[0][j] = *reinterpret_cast<const bf16x8 *>(T + gb_off[0] + j * 16 * ROWB);
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-            if (k2 == 0) {
-#pragma unroll
-                for (int i = 0; i < 2 * FC; ++i) fa[1][i] = *reinterpret_cast<const bf16x8 *>(T + ga_off[1] + i * 16 * ROWB);
-#pragma unroll
-                for (int j = 0; j < 2 * FP; ++j) fb[1][j] = *reinterpret_cast<const bf16x8 *>(T + gb_off[1] + j * 16 * ROWB);
-            }
-#pragma unroll
-            for (int i = 0; i < 2 * FC; ++i)
-#pragma unroll
-                for (int j = 0; j < 2 * FP; ++j)
-                    acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[k2][i], fb[k2][j], acc4[i][j], 0, 0, 0);
-        }
-    };
     auto compute_tile32 = [&](int buf) {
         const char *T = smem + buf * TILE_BYTES;
         // fragments of k-step kk+1 are fetched while the MFMAs of k-step kk run (two register sets)
@@ -374,10 +334,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         }
     };
 
-    auto compute_tile = [&](int buf) {
-        if constexpr (MF == 1) compute_tile16(buf);
-        else compute_tile32(buf);
-    };
+    auto compute_tile = [&](int buf) { compute_tile32(buf); };
 
     if constexpr (GLDS) {
         if (a.single_buf) {
@@ -459,27 +416,6 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
     float *bias_lds = reinterpret_cast<float *>(smem + a.bias_lds_off);
     if (tid < CT) bias_lds[tid] = bias_early;
     __syncthreads();
-    if constexpr (MF == 1) {
-#pragma unroll
-        for (int i = 0; i < 2 * FC; ++i) {
-            const int c_local = (wc * FC * 2 + i) * 16 + 4 * lq;  // 4 consecutive couts
-            const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + c_local);
-#pragma unroll
-            for (int j = 0; j < 2 * FP; ++j) {
-                const int p_local = (wp * FP * 2 + j) * 16 + l16;
-                float v0 = acc4[i][j][0] + bv.x, v1 = acc4[i][j][1] + bv.y, v2 = acc4[i][j][2] + bv.z, v3 = acc4[i][j][3] + bv.w;
-                if (a.relu == 1 && !a.res) {
-                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                } else if (GEN == 2 || (GEN == 1 && a.relu == 2)) {
-                    v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3);
-                }
-                uint2 pk;
-                pk.x = pk_bf16(v0, v1);
-                pk.y = pk_bf16(v2, v3);
-                *reinterpret_cast<uint2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
-            }
-        }
-    } else
 #pragma unroll
     for (int i = 0; i < FC; ++i) {
 #pragma unroll
@@ -536,10 +472,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
     }
 }
 
-template <int NT, int WC, int WP, int FC, int FP, int MODE, int MF = 0>
+template <int NT, int WC, int WP, int FC, int FP, int MODE>
 static int launch_conv(ConvArgs &a, hipStream_t s) {
     const bool cat_only = a.adv && a.os == 1 && !a.oy && !a.ox && a.Ho == a.Hf && a.Wo == a.Wf;
-    const bool plain = MODE == 2 && MF == 0 && (!a.adv || cat_only) && !a.res_up;
+    const bool plain = MODE == 2 && (!a.adv || cat_only) && !a.res_up;
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
     g_last_kernel = MODE == 1 ? MD_CONV_KERNEL_IGEMM_GENERIC_K : (CT == 128 && PT == 128 ? MD_CONV_KERNEL_IGEMM_128 :
                     (CT < 128 ? MD_CONV_KERNEL_IGEMM_SMALL_COUT : MD_CONV_KERNEL_OTHER));
@@ -556,9 +492,9 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
     a.pt_per_xcd = (a.n_ptiles + 7) / 8;
     const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
-    constexpr bool HAS_PLAIN = MODE == 2 && MF == 0;
-    auto k = conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, MF, 1>;
-    if (plain) k = a.relu == 2 ? conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, MF, HAS_PLAIN ? 2 : 1> : conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, MF, HAS_PLAIN ? 0 : 1>;
+    constexpr bool HAS_PLAIN = MODE == 2;
+    auto k = conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, 1>;
+    if (plain) k = a.relu == 2 ? conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, HAS_PLAIN ? 2 : 1> : conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, HAS_PLAIN ? 0 : 1>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return MD_ERR_HIP;
@@ -1224,7 +1160,10 @@ using namespace md;
 // Required weight padding for a given Cout (the tile the dispatcher will pick): exported so the
 // host packer pads consistently.
 extern "C" int md_conv2d_last_kernel(void) { return g_last_kernel; }
-namespace md { void md_note_conv_kernel(int id) { g_last_kernel = id; } }
+namespace md {
+void md_note_conv_kernel(int id) { g_last_kernel = id; }
+long long md_chunk_limit() { return g_chunk_limit; }
+}
 extern "C" long long md_conv2d_set_chunk_limit(long long bytes) {
     const long long old = g_chunk_limit;
     g_chunk_limit = bytes > 0 && bytes < 0x7fff0000LL ? bytes : 0x7fff0000LL;
@@ -1361,7 +1300,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     a.pointwise = a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad_top == 0 && a.pad_left == 0 && a.H == a.Ho && a.W == a.Wo;
     hipStream_t s = (hipStream_t)stream;
     // variant: 0 = auto (cost model below); 1 = register-staged 128x128; 2 = LDS-DMA 128x128 with two staging buffers;
-    // 5 = 128x128 on v_mfma 16x16x32; 11 = 128-cout halo kernel; 15 / 22 = ping-pong kernel (32x32x16 / 16x16x32 MFMA);
+    // 11 = 128-cout halo kernel; 15 / 22 = ping-pong kernel (32x32x16 / 16x16x32 MFMA);
     // 20 = LDS-DMA 128x128 with one staging buffer; 27 = 64-cout halo kernel; 17-19 / 25 = timing ablations / stamps, MD_DIAG
     // builds only (the product library answers MD_ERR_ARG)
     int variant = variant_override >= 0 ? variant_override : at->variant;
@@ -1437,7 +1376,6 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     // while this one is multiplied (512->512 @20x20, batch 32: +11 %)
     if (variant == 0 && sb_blocks <= 512 && a.Kpad / BK >= 16) a.single_buf = 0;
     if (variant == 1) return launch_conv<256, 2, 2, 2, 2, 0>(a, s);               // register-staged, 64-bit addressing
-    if (variant == 5 && fast) return launch_conv<256, 2, 2, 2, 2, 2, 1>(a, s);    // 128x128, 16x16x32 MFMA
     return fast ? launch_conv<256, 2, 2, 2, 2, 2>(a, s) : launch_conv<256, 2, 2, 2, 2, 1>(a, s);
 }
 

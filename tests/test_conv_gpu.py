@@ -43,7 +43,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 5, 11, 15, 16, 20, 22, 27])
+@pytest.mark.parametrize("variant", [0, 1, 2, 11, 15, 16, 20, 22, 27])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_conv_vs_torch_fp32(case, variant):
     from minddet_amd import nn_ops
@@ -57,7 +57,7 @@ def test_conv_vs_torch_fp32(case, variant):
     if use_bn:
         bn = (torch.rand((Cout,), generator=g) + 0.5, torch.randn((Cout,), generator=g) * 0.1,
               torch.randn((Cout,), generator=g) * 0.1, torch.rand((Cout,), generator=g) + 0.5, 1e-5)
-    korder = 1 if (variant in (2, 5, 11, 16, 27) and Cin % 64 == 0 and k > 1) else 0
+    korder = 1 if (variant in (2, 11, 16, 27) and Cin % 64 == 0 and k > 1) else 0
     if variant == 16:
         variant = 15  # the ping-pong kernel on korder-1 weights
     pc = nn_ops.pack_conv(w, bias=bias, bn=bn, stride=stride, pad=pad, relu=relu, korder=korder).to(DEV)
@@ -411,6 +411,17 @@ def test_fused_bottleneck_argument_checks_and_determinism():
         x64 = torch.zeros((1, 8, 16, 64), dtype=torch.bfloat16, device=DEV)
         _lib.call("md_bottleneck", [x64, b64.w1, b64.b12, b64.w2, b64.w3, b64.b3, torch.zeros((1, 8, 16, 256), dtype=torch.bfloat16, device=DEV),
                                     b64.wd, b64.bd, torch.zeros((1, 8, 16, 256), dtype=torch.bfloat16, device=DEV)])
+    # batches whose x tensor exceeds the DMA reach run as image chunks: same result through a lowered limit (5 images -> 2 + 2 + 1)
+    x5 = torch.randn((5, 16, 32, 256), generator=g).to(torch.bfloat16).to(DEV)
+    y5 = nn_ops.bottleneck(x5, blk)
+    lib = _lib.lib()
+    lib.md_conv2d_set_chunk_limit.restype = ctypes.c_longlong
+    old_lim = lib.md_conv2d_set_chunk_limit(ctypes.c_longlong(2 * 16 * 32 * 256 * 2 + 1))
+    try:
+        y5c = nn_ops.bottleneck(x5, blk)
+    finally:
+        lib.md_conv2d_set_chunk_limit(ctypes.c_longlong(old_lim))
+    assert torch.equal(y5, y5c)
     # blocks md_bottleneck does not take are not packed: the graph keeps the three-launch path for them
     p128 = nn_ops.pack_conv(torch.randn((128, 512, 1, 1)) * 0.05, relu=True).to(DEV)
     assert nn_ops.pack_bottleneck(p128, pc2, pc3) is None
