@@ -331,6 +331,22 @@ def main(argv=None):
 
         timed_extra["bottleneck"] = (orig_bottleneck, timed_bottleneck)
 
+    if hasattr(nn_ops, "conv1x1_dual"):
+        orig_dual = nn_ops.conv1x1_dual
+
+        def timed_dual(xa, xb, pk, **kw):
+            if _skip():
+                return orig_dual(xa, xb, pk, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig_dual(xa, xb, pk, **kw)
+            e1.record()
+            fl, byts = pk.flops_bytes(xa.shape[0], xa.shape[1], xa.shape[2])
+            records.append((e0, e1, fl, tuple(xa.shape[:3]) + (pk.ca + pk.cb,), pk.cout, 1, byts, last_kernel(), None, None))
+            return y
+
+        timed_extra["conv1x1_dual"] = (orig_dual, timed_dual)
+
     def instrument_on():
         nn_ops.conv2d, nn_ops.conv2d_head = timed_conv2d, timed_conv2d_head
         for k_, (_, tw) in timed_extra.items():

@@ -172,6 +172,19 @@ int md_conv2d(MD_AOT_ARGS);
  * pads Cout up to a multiple of it.  Pure function, callable without a GPU. */
 int md_conv2d_cout_tile(int cout);
 
+/* ONE 1x1 GEMM over the K-concatenation of two inputs: y = act(W . [x_a ; x_b sampled with stride_b] + bias [+ residual]).
+ * Replaces, in the first block of a ResNet stage (centernet/src/resnet.py:139-178 with `downsample`; _make_layer :214-224),
+ * conv3 + bn3 on the block's feature map AND the strided 1x1 downsample conv + bn on the block input AND their add:
+ * w = [w3 | wd] (both BN-folded), bias = b3 + bd.  The Cout-channel residual tensor of the layer-by-layer form is never written
+ * (-2 x Cout x 2 B per pixel of HBM traffic, one launch less); the sum is rounded to bf16 once instead of three times.
+ * in : x_a[N,Ho,Wo,Ca] bf16, x_b[N,Hb,Wb,Cb] bf16 (Ca, Cb multiples of 64; Ho = (Hb-1)/stride_b + 1), w[roundup(Cout,128), Ca+Cb] bf16,
+ *      bias[roundup(Cout,128)] f32, residual[N,Ho,Wo,Cout] bf16 | NULL ; out y[N,Ho,Wo,Cout] bf16 (Cout > 64). */
+typedef struct md_conv1x1_dual_attrs {
+    int32_t stride_b;   /* spatial stride of x_b (the block's stride) */
+    int32_t relu;       /* 0 none, 1 ReLU after the sum */
+} md_conv1x1_dual_attrs;
+int md_conv1x1_dual(MD_AOT_ARGS);
+
 /* Conv (Cout = 256) + bias + ReLU followed by a 1x1 conv with <= 16 output channels (the RPN head of the two-stage
  * detectors: shared 3x3 conv -> [objectness | deltas]); where the 256x256 ping-pong kernel applies, the 256-channel
  * intermediate never leaves the CU (second GEMM straight from the epilogue image), otherwise two launches through a

@@ -81,6 +81,10 @@ struct ConvArgs {
                             //    (the FPN top-down add fused into the lateral 1x1 conv); plain addressing only
     int Xs;                 // pixel stride of x in channels (== Cin unless the input is a channel slice of a wider tensor;
                             // a.x then already points at the slice's first channel)
+    // DUAL (md_conv1x1_dual): K tiles >= nk_a come from a second tensor x2 [N,H2,W2,Xs2] read at (ho * stride2, wo * stride2)
+    const uint16_t *x2;
+    unsigned x2_bytes;
+    int H2, W2, Xs2, stride2, nk_a;
     int Rs;                 // 0: the residual has the output's layout; > 0: residual pixel m, channel c at m*Rs + c (a channel
                             // slice of a wider [N,Ho,Wo,Rs] tensor, a.res pointing at its first channel)
 };
@@ -145,7 +149,9 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 
 // instantiations for ReLU-or-none / SiLU layers whose output is a whole tensor or a channel range of a concat buffer
 // (offset = m * Ctot + c_off + c): the division-heavy address code of the general epilogue is compiled out (it was 2/3 of the
 // kernel's instructions) and the activation is a compile-time choice.
-template <int NT, int WC, int WP, int FC, int FP, int MODE, int GEN = 1>
+// DUAL 1 (MODE 2, 1x1): the K axis is the concatenation of TWO input tensors -- K tiles < a.nk_a from x (pixel = output pixel), the rest
+// from x2 sampled with stride a.stride2 (md_conv1x1_dual: a bottleneck's expand conv and its strided downsample conv as ONE GEMM).
+template <int NT, int WC, int WP, int FC, int FP, int MODE, int GEN = 1, int DUAL = 0>
 __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr bool GLDS = MODE != 0;
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
@@ -255,6 +261,21 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         a_off0 = ((cout0 + row0) * a.Kpad + chunk * 8) * 2;
     }
     const int wrow = wave * 8;  // first row of this wave's 8-row group inside a staging pass
+    __amdgpu_buffer_rsrc_t rs_x2 = rs_x;
+    unsigned p_base2[DUAL ? B_ROWS : 1];
+    if constexpr (DUAL != 0) {
+        rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.x2, 0, a.x2_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) {
+            const int m = pix0 + row0 + RPP * i;
+            p_base2[i] = OOR;
+            if (m < a.M) {
+                const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
+                const int ho = r / a.Wo, wo = r - ho * a.Wo;
+                p_base2[i] = (unsigned)((((n * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2) * a.Xs2) * 2 + chunk * 16);
+            }
+        }
+    }
     auto dma_tile = [&](int kt, int buf) {
         typedef __attribute__((address_space(3))) void lds_void;
         char *A = smem + buf * TILE_BYTES, *B = A + CT * ROWB;
@@ -262,6 +283,15 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 2) void conv_igemm_kernel(ConvA
         for (int i = 0; i < A_ROWS; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(A + (wrow + RPP * i) * ROWB), 16,
                                                      a_off0 + i * (RPP * a.Kpad * 2), kt * (BK * 2), 0, 0);
+        if constexpr (DUAL != 0) {
+            if (kt >= a.nk_a) {   // second tensor: 64-channel chunk kt - nk_a of the strided pixel
+#pragma unroll
+                for (int i = 0; i < B_ROWS; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_void *)(B + (wrow + RPP * i) * ROWB), 16, (int)p_base2[i],
+                                                             (kt - a.nk_a) * (BK * 2), 0, 0);
+                return;
+            }
+        }
         if constexpr (MODE == 2) {
             const int soff = ((s_kh * a.W + s_kw) * a.Xs + s_cc0 * 8) * 2;
 #pragma unroll
@@ -503,6 +533,25 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
+
+// 128 x 128 single-buffer kernel on the K-concatenation of two inputs (md_conv1x1_dual)
+static int launch_conv_dual(ConvArgs &a, hipStream_t s) {
+    constexpr int CT = 128, PT = 128;
+    g_last_kernel = MD_CONV_KERNEL_IGEMM_128;
+    a.n_ctiles = (a.Cout + CT - 1) / CT;
+    a.n_ptiles = (a.M + PT - 1) / PT;
+    a.single_buf = 1;
+    const int tile_bytes = (CT + PT) * ROWB;
+    constexpr int ep_bytes = PT * (CT * 2 + 16);
+    a.bias_lds_off = tile_bytes > ep_bytes ? tile_bytes : ep_bytes;
+    const int lds = a.bias_lds_off + CT * 4;
+    a.pt_per_xcd = (a.n_ptiles + 7) / 8;
+    const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
+    if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
+    auto k = conv_igemm_kernel<256, 2, 2, 2, 2, 2, 0, 1>;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with HALO REUSE.
@@ -1424,4 +1473,57 @@ extern "C" int md_conv2d_head(MD_AOT_ARGS) {
     const char *dt1[5] = {"bfloat16", "bfloat16", "float32", nullptr, "bfloat16"};
     void *p1[5] = {tmp.ptr, params[3], params[4], nullptr, params[5]};
     return conv2d_entry(5, p1, nd1, sh1, dt1, stream, &a1, nullptr);
+}
+
+// y = act(W . [x_a ; x_b sampled with stride] + bias [+ residual]): ONE 1x1 GEMM over the K-concatenation of two inputs.
+// The use: the first block of a ResNet stage (centernet/src/resnet.py:139-178 with `downsample`, built by _make_layer :214-224):
+// out = relu(bn3(conv3(t2)) + bn_d(conv_d(x))) -- conv3 is 1x1 on the block's own feature map, conv_d a 1x1 conv with the block's stride
+// on its input.  [W3 | Wd] . [t2 ; x_strided] + (b3 + bd) is the same sum in one accumulator: no downsample launch, no Cout-channel
+// residual tensor written and re-read.  (One bf16 rounding instead of the three of the layer-by-layer path.)
+// in : x_a[N,Ho,Wo,Ca] bf16 (Ca % 64 == 0), x_b[N,Hb,Wb,Cb] bf16 (Cb % 64 == 0, Ho == (Hb-1)/stride_b + 1), w[Cout_pad, Ca + Cb] bf16,
+//      bias[Cout_pad] f32, residual[N,Ho,Wo,Cout] bf16 | NULL ; out y[N,Ho,Wo,Cout] bf16 (Cout > 64).  extra: md_conv1x1_dual_attrs
+extern "C" int md_conv1x1_dual(MD_AOT_ARGS) {
+    if (nparam != 6) return MD_ERR_NPARAM;
+    if (!params || !extra || !ndims || !shapes || !params[2] || !params[3]) return MD_ERR_ARG;
+    if (!dtype_is(dtypes, 0, "bfloat16") || !dtype_is(dtypes, 1, "bfloat16") || !dtype_is(dtypes, 2, "bfloat16") ||
+        !dtype_is(dtypes, 3, "float32") || !dtype_is(dtypes, 5, "bfloat16") || (params[4] && !dtype_is(dtypes, 4, "bfloat16")))
+        return MD_ERR_ARG;
+    if (ndims[0] != 4 || ndims[1] != 4 || ndims[2] != 2 || ndims[5] != 4) return MD_ERR_ARG;
+    const md_conv1x1_dual_attrs *at = (const md_conv1x1_dual_attrs *)extra;
+    const int64_t N = shapes[0][0], Ho = shapes[0][1], Wo = shapes[0][2], Ca = shapes[0][3];
+    const int64_t Hb = shapes[1][1], Wb = shapes[1][2], Cb = shapes[1][3], Cout = shapes[5][3];
+    if (at->stride_b < 1 || at->relu < 0 || at->relu > 1 || Ca % 64 || Cb % 64 || Ca < 64 || Cb < 64 || Cout % 8 || Cout <= 64) return MD_ERR_ARG;
+    if (shapes[1][0] != N || shapes[5][0] != N || shapes[5][1] != Ho || shapes[5][2] != Wo || Hb < 1 || Wb < 1 ||
+        Ho != (Hb - 1) / at->stride_b + 1 || Wo != (Wb - 1) / at->stride_b + 1)
+        return MD_ERR_ARG;
+    const int64_t cout_pad = (Cout + 127) / 128 * 128;
+    if (shapes[2][0] != cout_pad || shapes[2][1] != Ca + Cb || numel(ndims, shapes, 3) != cout_pad) return MD_ERR_ARG;
+    if (params[4] && (ndims[4] != 4 || numel(ndims, shapes, 4) != N * Ho * Wo * Cout)) return MD_ERR_ARG;
+    if (N * Ho * Wo == 0) return MD_OK;
+    if (!params[0] || !params[1] || !params[5]) return MD_ERR_ARG;
+    if (Hb > 32000 || Wb > 32000) return MD_ERR_SIZE;
+    const long long xa_img = Ho * Wo * Ca * 2, xb_img = Hb * Wb * Cb * 2, w_bytes = cout_pad * (Ca + Cb) * 2;
+    const long long big = xa_img > xb_img ? xa_img : xb_img;
+    if (big >= 0x7fff0000LL || w_bytes >= 0x7fff0000LL) return MD_ERR_SIZE;
+    const long long lim = g_chunk_limit > big ? g_chunk_limit : big;
+    const long long per = lim / big < N ? lim / big : N;     // images per launch: both inputs stay inside the DMA reach
+    for (long long n0 = 0; n0 < N; n0 += per) {
+        const long long nn = N - n0 < per ? N - n0 : per;
+        ConvArgs a = {};
+        a.x = (const uint16_t *)params[0] + n0 * Ho * Wo * Ca;
+        a.x2 = (const uint16_t *)params[1] + n0 * Hb * Wb * Cb;
+        a.w = (const uint16_t *)params[2]; a.bias = (const float *)params[3];
+        a.res = params[4] ? (const uint16_t *)params[4] + n0 * Ho * Wo * Cout : nullptr;
+        a.y = (uint16_t *)params[5] + n0 * Ho * Wo * Cout;
+        a.N = (int)nn; a.H = (int)Ho; a.W = (int)Wo; a.Cin = (int)Ca; a.Xs = (int)Ca; a.Cout = (int)Cout; a.Ho = (int)Ho; a.Wo = (int)Wo;
+        a.kh = a.kw = 1; a.stride = 1; a.pad = 0; a.relu = at->relu;
+        a.Kpad = (int)(Ca + Cb); a.Kreal = a.Kpad; a.cpt = (int)(Ca / 8);
+        a.M = (int)(nn * Ho * Wo);
+        a.x_bytes = (unsigned)(nn * xa_img); a.w_bytes = (unsigned)w_bytes; a.x2_bytes = (unsigned)(nn * xb_img);
+        a.Hf = (int)Ho; a.Wf = (int)Wo; a.Ctot = (int)Cout; a.os = 1; a.pointwise = 1;
+        a.H2 = (int)Hb; a.W2 = (int)Wb; a.Xs2 = (int)Cb; a.stride2 = at->stride_b; a.nk_a = (int)(Ca / 64);
+        const int rc = launch_conv_dual(a, (hipStream_t)stream);
+        if (rc != MD_OK) return rc;
+    }
+    return MD_OK;
 }

@@ -23,6 +23,8 @@ RPN_OVERLAP = os.environ.get("MD_RPN_OVERLAP", "1") == "1"
 # stride-1 bottleneck blocks with 64 mid channels (ResNet-50 / 101 stage 1) as ONE md_bottleneck launch instead of three md_conv2d
 # launches (bit-identical results; MD_FUSE_BLOCKS=0 keeps the layer-by-layer path for A/B)
 FUSE_BLOCKS = os.environ.get("MD_FUSE_BLOCKS", "1") == "1"
+# first block of the later stages: conv3 + the strided 1x1 downsample conv as one K-concatenated GEMM (md_conv1x1_dual; MD_FUSE_DUAL=0: two launches)
+FUSE_DUAL = os.environ.get("MD_FUSE_DUAL", "1") == "1"
 RPN_FUSED_HEAD = os.environ.get("MD_RPN_FUSED", "1") == "1"  # 0: two md_conv2d launches per level (A/B)
 
 
@@ -114,6 +116,7 @@ class Bottleneck:
         self.conv3 = ConvModule(init, planes, planes * 4, 1, relu=True)  # ReLU after the residual add
         self.downsample = downsample
         self._fused = False
+        self._dual = False
 
     def modules(self):
         return [self.conv1, self.conv2, self.conv3] + ([self.downsample] if self.downsample else [])
@@ -128,6 +131,12 @@ class Bottleneck:
                 # first block's 1x1 downsample conv is computed from the same x tile
                 res = self.downsample(x) if (self.downsample is not None and self._fused.wd is None) else None
                 return nn_ops.bottleneck(x, self._fused, residual=res)
+        if FUSE_DUAL and self.downsample is not None:
+            # first block of a stage: conv3 and the (strided) 1x1 downsample conv as ONE GEMM over [t2 ; x] (md_conv1x1_dual)
+            if self._dual is False:
+                self._dual = nn_ops.pack_dual(self.conv3.packed, self.downsample.packed)
+            if self._dual is not None:
+                return nn_ops.conv1x1_dual(self.conv2(self.conv1(x)), x, self._dual)
         residual = self.downsample(x) if self.downsample is not None else x
         return self.conv3(self.conv2(self.conv1(x)), residual=residual)
 

@@ -189,6 +189,44 @@ def bottleneck(x, blk, residual=None, out=None):
     return out
 
 
+class _DualAttrs(ctypes.Structure):
+    _fields_ = [("stride_b", ctypes.c_int32), ("relu", ctypes.c_int32)]
+
+
+class PackedDual:
+    """[w3 | wd] and b3 + bd of a bottleneck's expand conv and its 1x1 downsample conv (md_conv1x1_dual)."""
+
+    def __init__(self, pc3, pd):
+        self.ca, self.cb, self.cout, self.stride, self.relu = pc3.cin, pd.cin, pc3.cout, pd.stride, int(pc3.relu)
+        self.w = torch.cat([pc3.w[:, :pc3.cin], pd.w[:, :pd.cin]], dim=1).contiguous()
+        self.bias = (pc3.bias + pd.bias).contiguous()
+        self.cin_real = pc3.cin_real + pd.cin_real
+
+    def flops_bytes(self, n, ho, wo):
+        px = n * ho * wo
+        return 2.0 * px * self.cout * (self.ca + self.cb), 2.0 * (px * (self.ca + self.cb + self.cout) + self.w.numel())
+
+
+def pack_dual(pc3, pd):
+    """-> PackedDual when conv3 (1x1, stride 1) and the downsample conv (1x1, stride s, no activation) can run as one md_conv1x1_dual
+    GEMM, else None."""
+    ok = (pc3.kh == 1 and pc3.stride == 1 and pc3.pad == 0 and pc3.relu in (0, 1) and pd.kh == 1 and pd.pad == 0 and pd.relu == 0 and
+          pc3.cout == pd.cout and pc3.cout > 64 and pc3.cin % 64 == 0 and pd.cin % 64 == 0 and cout_tile(pc3.cout) == 128 and
+          tuple(pc3.w.shape) == (pd.w.shape[0], pc3.cin) and pd.w.shape[1] == pd.cin)
+    return PackedDual(pc3, pd) if ok else None
+
+
+def conv1x1_dual(xa, xb, pk, out=None):
+    """y = act(w3 . xa + wd . xb[:, ::s, ::s] + b3 + bd) in one launch (xa [N,Ho,Wo,Ca], xb [N,Hb,Wb,Cb])."""
+    n, ho, wo, ca = xa.shape
+    if ca != pk.ca or xb.shape[3] != pk.cb:
+        raise _lib.MindDetHipError(f"conv1x1_dual: inputs have {ca} / {xb.shape[3]} channels, packed for {pk.ca} / {pk.cb}")
+    if out is None:
+        out = torch.empty((n, ho, wo, pk.cout), dtype=torch.bfloat16, device=xa.device)
+    _lib.call("md_conv1x1_dual", [xa, xb, pk.w, pk.bias, None, out], extra=_DualAttrs(int(pk.stride), int(pk.relu)))
+    return out
+
+
 class PackedConvT:
     """A transposed conv as s*s sub-pixel convs on the MFMA kernel (one launch per output parity)."""
 

@@ -437,14 +437,70 @@ def test_resnet_with_fused_blocks_equals_layer_by_layer():
     x8 = torch.zeros((2, 96, 160, 8))
     x8[..., :3] = torch.randn((2, 96, 160, 3), generator=g)
     xb = x8.to(torch.bfloat16).to(DEV)
-    old = graphs.FUSE_BLOCKS
+    old, old_d = graphs.FUSE_BLOCKS, graphs.FUSE_DUAL
     try:
-        graphs.FUSE_BLOCKS = True
+        graphs.FUSE_BLOCKS = graphs.FUSE_DUAL = True
         fused = bb(xb)
         assert all(b._fused is not None for b in bb.stages[0]) and all(b._fused in (None, False) for st in bb.stages[1:] for b in st)
-        graphs.FUSE_BLOCKS = False
+        assert all(st[0]._dual is not None for st in bb.stages[1:])
+        graphs.FUSE_BLOCKS = graphs.FUSE_DUAL = False
         plain = bb(xb)
     finally:
-        graphs.FUSE_BLOCKS = old
-    for f, p in zip(fused, plain):
-        assert torch.equal(f, p)
+        graphs.FUSE_BLOCKS, graphs.FUSE_DUAL = old, old_d
+    assert torch.equal(fused[0], plain[0])     # stage 1: md_bottleneck is bit-identical to the layer-by-layer launches
+    for f, p in zip(fused[1:], plain[1:]):     # later stages: the first block's expand + downsample GEMM rounds once instead of three times
+        assert (f.float() - p.float()).abs().max().item() <= 0.05 * max(p.float().abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("cfg", [("stage2", 2, 40, 56, 128, 256, 512, 2), ("stage3", 1, 25, 42, 256, 512, 1024, 2), ("stage4_ragged", 3, 13, 21, 512, 1024, 2048, 2),
+                                 ("stride1", 2, 19, 23, 64, 128, 256, 1), ("odd_input", 1, 9, 15, 64, 64, 192, 2)], ids=lambda c: c[0])
+def test_conv1x1_dual_equals_expand_plus_downsample(cfg):
+    """md_conv1x1_dual ([w3 | wd] . [t2 ; x strided] + b3 + bd, ReLU) against the two md_conv2d launches it replaces (downsample conv ->
+    residual of the expand conv) and against fp32 torch.  The fused form rounds the sum to bf16 once instead of three times, so the
+    comparison with the layer-by-layer path allows what those roundings can move (bf16 ulps of the operands)."""
+    from minddet_amd import nn_ops
+
+    name, N, Ho, Wo, Ca, Cb, Cout, s = cfg
+    g = torch.Generator().manual_seed(len(name) + Cout)
+    Hb, Wb = (Ho - 1) * s + 1 + (1 if name == "stage2" else 0) * (s - 1), (Wo - 1) * s + 1 + (1 if name == "stage2" else 0) * (s - 1)
+    w3 = torch.randn((Cout, Ca, 1, 1), generator=g) * (1.0 / Ca) ** 0.5
+    wd = torch.randn((Cout, Cb, 1, 1), generator=g) * (1.0 / Cb) ** 0.5
+    b3, bd = torch.randn((Cout,), generator=g) * 0.1, torch.randn((Cout,), generator=g) * 0.1
+    pc3 = nn_ops.pack_conv(w3, bias=b3, relu=True).to(DEV)
+    pd = nn_ops.pack_conv(wd, bias=bd, stride=s, relu=False).to(DEV)
+    pk = nn_ops.pack_dual(pc3, pd)
+    assert pk is not None and pk.stride == s
+    xa = torch.randn((N, Ho, Wo, Ca), generator=g).to(torch.bfloat16).to(DEV)
+    xb = torch.randn((N, Hb, Wb, Cb), generator=g).to(torch.bfloat16).to(DEV)
+    ref = nn_ops.conv2d(xa, pc3, residual=nn_ops.conv2d(xb, pd))
+    y = nn_ops.conv1x1_dual(xa, xb, pk)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    t = F.conv2d(xa.float().cpu().permute(0, 3, 1, 2), w3.to(torch.bfloat16).float(), None) + \
+        F.conv2d(xb.float().cpu().permute(0, 3, 1, 2), wd.to(torch.bfloat16).float(), None, stride=s) + (b3 + bd).view(1, -1, 1, 1)
+    t = torch.relu(t).permute(0, 2, 3, 1)
+    err = (y.float().cpu() - t).abs()
+    assert (err <= 2.0 ** -7 * t.abs() + 2e-2).all(), err.max().item()                 # one bf16 rounding of the exact sum (+ fp32 accumulation order)
+    d = (y.float() - ref.float()).abs().cpu()
+    assert (d <= 3 * 2.0 ** -7 * t.abs() + 5e-2).all(), d.max().item()                # the three roundings of the layer-by-layer path
+    y2 = nn_ops.conv1x1_dual(xa, xb, pk)
+    assert torch.equal(y, y2)
+
+
+def test_conv1x1_dual_argument_checks():
+    from minddet_amd import _lib, nn_ops
+
+    pc3 = nn_ops.pack_conv(torch.randn((256, 64, 1, 1)) * 0.1, bias=torch.zeros(256), relu=True).to(DEV)
+    pd = nn_ops.pack_conv(torch.randn((256, 128, 1, 1)) * 0.1, bias=torch.zeros(256), stride=2, relu=False).to(DEV)
+    pk = nn_ops.pack_dual(pc3, pd)
+    xa = torch.zeros((1, 8, 8, 64), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(_lib.MindDetHipError, match="rc=2"):          # x_b's size does not give x_a's size at this stride
+        nn_ops.conv1x1_dual(xa, torch.zeros((1, 20, 20, 128), dtype=torch.bfloat16, device=DEV), pk)
+    with pytest.raises(_lib.MindDetHipError):                        # channel mismatch is caught by the wrapper
+        nn_ops.conv1x1_dual(xa, torch.zeros((1, 15, 15, 64), dtype=torch.bfloat16, device=DEV), pk)
+    assert nn_ops.conv1x1_dual(torch.zeros((0, 8, 8, 64), dtype=torch.bfloat16, device=DEV),
+                               torch.zeros((0, 15, 15, 128), dtype=torch.bfloat16, device=DEV), pk).shape == (0, 8, 8, 256)
+    p3x3 = nn_ops.pack_conv(torch.randn((256, 128, 3, 3)) * 0.1, stride=2, pad=1).to(DEV)
+    assert nn_ops.pack_dual(pc3, p3x3) is None                       # only 1x1 downsample convs
+    p64 = nn_ops.pack_conv(torch.randn((64, 64, 1, 1)) * 0.1, relu=True).to(DEV)
+    assert nn_ops.pack_dual(p64, nn_ops.pack_conv(torch.randn((64, 64, 1, 1)) * 0.1).to(DEV)) is None   # Cout <= 64: other tile shape
