@@ -218,13 +218,17 @@ enum {
     MD_CONV_KERNEL_IGEMM_GENERIC_K = 4, /* conv_igemm_kernel generic K walk (the 7x7 stem) */
     MD_CONV_KERNEL_HALO = 5,            /* conv3x3_halo_kernel (3x3 layers with Cout <= 64; variant 11 / 27) */
     MD_CONV_KERNEL_OTHER = 6,           /* A/B variants */
-    MD_CONV_KERNEL_BOTTLENECK = 7       /* bottleneck64_kernel (md_bottleneck) */
+    MD_CONV_KERNEL_BOTTLENECK = 7,      /* bottleneck64_kernel (md_bottleneck) */
+    MD_CONV_KERNEL_STREAM_1X1 = 8       /* conv1x1_stream_kernel: weight-stationary pointwise layers, K <= 512 */
 };
 int md_conv2d_last_kernel(void);
 /* md_conv2d runs a batch whose activation tensor exceeds `bytes` (default and maximum: 2 GiB - 64 KiB, the reach of the
  * kernels' 32-bit LDS-DMA offsets) as consecutive image chunks on the same stream.  Returns the previous limit; tests
  * lower it to exercise the chunked path on small tensors. */
 long long md_conv2d_set_chunk_limit(long long bytes);
+/* Tools only: the number of workgroup rounds conv1x1_stream_kernel cuts a layer's pixel range into (default 1 = one resident
+ * workgroup per slot streams its whole share).  Returns the previous value. */
+int md_conv2d_set_stream_rounds(int rounds);
 
 /* ------------------------------------------------------------------------------------------
  * Streaming NHWC bf16 helpers between convs

@@ -47,6 +47,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 struct ConvArgs {
     const uint16_t *x;      // [N,H,W,Cin]
@@ -551,6 +552,245 @@ static int launch_conv_dual(ConvArgs &a, hipStream_t s) {
     auto k = conv_igemm_kernel<256, 2, 2, 2, 2, 2, 0, 1>;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// conv1x1_stream_kernel -- pointwise conv (1x1 / stride 1 / pad 0) with K = Cin <= 512, WEIGHT-STATIONARY.
+//
+// Why (r02, profiles/r02_conv_layers.json + DESIGN 6b): the 1x1 expand / reduce / lateral layers of the ResNet stages are HBM-bound
+// (256->1024 + residual: 4.6 KB of activations per pixel against 0.5 MFLOP), yet the 128x128 kernel runs them at 3.9-5.1 TB/s: each
+// of its workgroups re-stages its weight tile (as many bytes as the activation tile at K = 256) and re-reads the activation tile
+// once per cout tile through the CU's vector-memory path, and its K loop is a chain of dependent round trips.  Here the weights of
+// a (cout tile) never move after the prologue: each of the 4 waves keeps its CB x 32 cout rows x K as MFMA A fragments in REGISTERS
+// (K = 256, CB = 2: 128 VGPRs), and the workgroup streams consecutive 32-pixel tiles past them:
+//   * activations: one LDS-DMA stream into a ring of NR slots (32 px x K), requested NR - 1 tiles ahead, retired with counted
+//     vmcnt + one raw s_barrier per tile; B fragments are conflict-free ds_read_b128 (16-B chunk index XOR row & 15, applied to the
+//     DMA's source chunk and to the reads);
+//   * residual: LDS-DMAed straight INTO the wave's private epilogue image (source chunks XOR-swizzled) one tile ahead; the epilogue
+//     adds it in place in accumulator layout (each 8-byte cell is read and re-written by the same lane), so it costs no registers
+//     and no second image;
+//   * output: the image leaves as whole 16-B / 128-B-line non-temporal buffer stores.
+// Every global access goes through a buffer descriptor re-based per tile (scalar 64-bit math only), so rows past M read zeros /
+// drop their stores by the hardware range check and no tensor-size limit applies.
+// Bytes through the CU's vector memory path per 32 px x 256 cout: x 16 K + residual 16 K + y 16 K = 48 KiB, against 96 KiB for the
+// same outputs on the 128x128 kernel.  Rounds exactly where conv_igemm_kernel rounds (conv + bias -> bf16, + residual -> bf16).
+// ------------------------------------------------------------------------------------------------------------
+#define MD_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+template <int K, int CB, bool SILU, bool RES>
+__global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int tpw, int n_chunks, int chunks_per_xcd) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr int KS = K / 16, RB = K * 2;          // MFMA k-steps, bytes per activation row
+    constexpr int PT = 32, SLOT = PT * RB;          // pixels per tile, bytes per ring slot
+    constexpr int NR = K == 512 ? 2 : (K == 128 ? 4 : 3), D = NR - 1;   // ring slots, tiles of look-ahead
+    constexpr int ND = SLOT / 4096;                 // x DMA instructions per wave and tile (1 KiB each)
+    constexpr int RPI = RB >= 1024 ? 1 : 1024 / RB; // tile rows per DMA instruction
+    constexpr int CW = CB * 32;                     // couts per wave (4 waves: CT = 4 * CW)
+    constexpr int CPP = CB * 4, EROW = CPP * 16;    // 16-B chunks / bytes per row of the wave's epilogue image [32 px][CW]
+    constexpr int EW = PT * EROW, NE = EW / 1024;   // image bytes; 1-KiB pieces = residual DMAs = store instructions per tile
+    constexpr int RPE = 1024 / EROW;                // image rows per piece
+    constexpr int ESH = CPP == 8 ? 1 : 2;           // image swizzle: chunk ^= (row >> ESH) & (CPP - 1)
+    constexpr int NRES = RES ? NE : 0;
+    static_assert(K % 128 == 0 && K <= 512 && CB * K <= 512, "weights must fit 128 registers per lane");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *ring = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    char *E = smem + NR * SLOT + wave * EW;
+    float *bias_lds = reinterpret_cast<float *>(smem + NR * SLOT + 4 * EW);
+
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+    const int ct = slot_id % a.n_ctiles, chunk = xcd * chunks_per_xcd + slot_id / a.n_ctiles;
+    if (chunk >= n_chunks) return;
+    const int t0 = chunk * tpw;
+    const int nt = a.n_ptiles - t0 < tpw ? a.n_ptiles - t0 : tpw;
+    if (nt <= 0) return;
+    const int cout_w = ct * (4 * CW) + wave * CW;   // this wave's first output channel
+    const int r_stride = a.Rs ? a.Rs : a.Ctot;      // residual pixel stride (channels)
+    const int r_c0 = a.Rs ? cout_w : a.c_off + cout_w;
+    const int y_c0 = a.c_off + cout_w;
+
+    // ---- per-lane offsets, constant for the whole launch
+    unsigned xoff[ND];      // x DMA i of this wave: tile row, source chunk (swizzled)
+    int xdst[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int j = wave * ND + i, byte = lane * 16;
+        const int row = j * RPI + (RB >= 1024 ? 0 : byte / RB), pc = (byte % RB) >> 4;
+        xoff[i] = (unsigned)(row * a.Xs * 2 + ((pc ^ (row & 15)) << 4));
+        xdst[i] = j * 1024;
+    }
+    unsigned yoff[NE], roff[NE];   // image piece i: row = i * RPE + lane / CPP, physical chunk lane % CPP holds logical chunk ^ swizzle
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int row = i * RPE + lane / CPP, lc = (lane % CPP) ^ ((row >> ESH) & (CPP - 1));
+        yoff[i] = (unsigned)(row * a.Ctot * 2 + lc * 16);
+        roff[i] = (unsigned)(row * r_stride * 2 + lc * 16);
+    }
+    int foff[8];            // B fragment of k-step s: ring slot + foff[s & 7] + (s >> 3) * 256
+#pragma unroll
+    for (int j = 0; j < 8; ++j) foff[j] = lr * RB + (((2 * j + lh) ^ (lr & 15)) << 4);
+    const int eswz = (lr >> ESH) & (CPP - 1);
+
+    // ---- per-tile descriptors (scalar).  A tile index past this workgroup's range gets an EMPTY descriptor: its DMAs are still
+    // issued (zero fill of a slot nobody reads), so every wave's vector-memory queue has the same shape in every iteration and
+    // the waits below are compile-time counts.
+    auto clip = [](long long rem) { return (int)(rem > 0x7fffffffLL ? 0x7fffffffLL : (rem < 0 ? 0 : rem)); };
+    auto x_desc = [&](int t) {
+        const long long b = (long long)(t0 + t) * PT * a.Xs * 2;
+        const long long rem = t < nt ? (long long)a.x_bytes - b : 0;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)a.x + (t < nt ? b : 0)), 0, clip(rem), 0x00020000);
+    };
+    auto r_desc = [&](int t) {
+        const long long m0 = t < nt ? (long long)(t0 + t) * PT : 0;
+        const long long rem = t < nt ? ((long long)a.M - m0) * r_stride * 2 - r_c0 * 2 : 0;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(a.res + m0 * r_stride + r_c0), 0, clip(rem), 0x00020000);
+    };
+    auto y_desc = [&](int t) {
+        const long long m0 = (long long)(t0 + t) * PT;
+        const long long rem = ((long long)a.M - m0) * a.Ctot * 2 - y_c0 * 2;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + m0 * a.Ctot + y_c0), 0, clip(rem), 0x00020000);
+    };
+    auto dma_x = [&](int t, int slot) {
+        __amdgpu_buffer_rsrc_t rs = x_desc(t);
+        char *dst = ring + slot * SLOT;
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(dst + xdst[i]), 16, (int)xoff[i], 0, 0, 0);
+    };
+    auto dma_res = [&](int t) {
+        __amdgpu_buffer_rsrc_t rs = r_desc(t);
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(E + i * 1024), 16, (int)roff[i], 0, 0, 2);
+    };
+
+    // ---- prologue: the first D activation tiles and the first residual tile are requested BEFORE the weights
+#pragma unroll
+    for (int t = 0; t < D; ++t) dma_x(t, t);
+    if constexpr (RES) dma_res(0);
+    if (tid < 4 * CW) bias_lds[tid] = a.bias[ct * (4 * CW) + tid];
+    bf16x8 wr[CB][KS];
+#pragma unroll
+    for (int b = 0; b < CB; ++b)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            wr[b][s] = *reinterpret_cast<const bf16x8 *>(a.w + (size_t)(cout_w + b * 32 + lr) * a.Kpad + s * 16 + lh * 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int s_cur = 0, s_new = D;    // ring slot of tile t / of tile t + D
+    for (int t = 0; t < nt; ++t) {
+        // x tile t was requested D iterations ago; behind it in this wave's queue: per iteration NE stores and NRES residual DMAs,
+        // and (D - 1 times) the ND pieces of a later x tile
+        __builtin_amdgcn_sched_barrier(0);
+        MD_WAIT_VMCNT(D * (NE + NRES) + (D - 1) * ND);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        dma_x(t + D, s_new);                // that slot was last read in iteration t - 1: every wave is past it (barrier)
+
+        const char *S = ring + s_cur * SLOT;
+        f32x16 acc[CB];
+#pragma unroll
+        for (int b = 0; b < CB; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+        bf16x8 fb[2];
+        fb[0] = *reinterpret_cast<const bf16x8 *>(S + foff[0]);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) fb[(s + 1) & 1] = *reinterpret_cast<const bf16x8 *>(S + foff[(s + 1) & 7] + ((s + 1) >> 3) * 256);
+#pragma unroll
+            for (int b = 0; b < CB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[b][s], fb[s & 1], acc[b], 0, 0, 0);
+        }
+        s_cur = s_cur + 1 == NR ? 0 : s_cur + 1;
+        s_new = s_new + 1 == NR ? 0 : s_new + 1;
+
+        // ---- epilogue on the wave's private image: residual (already there, behind it only this iteration's x pieces) +
+        // bf16(acc + bias), in place.  Every LDS access below uses a builtin vector type: hipcc's waitcnt pass puts an
+        // s_waitcnt vmcnt(0) in front of an LDS access WITHOUT type-based alias info while LDS-DMAs are pending (seen with
+        // float4 / uint2: it drained the x look-ahead every tile); the counted waits here are the synchronisation.
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (RES) MD_WAIT_VMCNT(ND);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < CB; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + wave * CW + b * 32 + 8 * g + 4 * lh);
+                f32x2 s01 = (f32x2){acc[b][4 * g + 0], acc[b][4 * g + 1]} + (f32x2){bv.x, bv.y};
+                f32x2 s23 = (f32x2){acc[b][4 * g + 2], acc[b][4 * g + 3]} + (f32x2){bv.z, bv.w};
+                if (SILU) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
+                u32x2 pk;
+                pk.x = pk_bf16(s01.x, s01.y);
+                pk.y = pk_bf16(s23.x, s23.y);
+                u32x2 *cell = reinterpret_cast<u32x2 *>(E + lr * EROW + (((4 * b + g) ^ eswz) << 4) + 8 * lh);
+                if constexpr (RES) {
+                    const u32x2 rv = *cell;
+                    const f32x2 a01 = (f32x2){__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u)} +
+                                      (f32x2){__uint_as_float(rv.x << 16), __uint_as_float(rv.x & 0xffff0000u)};
+                    const f32x2 a23 = (f32x2){__uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)} +
+                                      (f32x2){__uint_as_float(rv.y << 16), __uint_as_float(rv.y & 0xffff0000u)};
+                    pk.x = pk_bf16(a01.x, a01.y);
+                    pk.y = pk_bf16(a23.x, a23.y);
+                }
+                if (a.relu == 1) { pk.x = pk_relu_bf16(pk.x); pk.y = pk_relu_bf16(pk.y); }
+                *cell = pk;
+            }
+        __amdgpu_buffer_rsrc_t ry = y_desc(t);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(E + i * 1024 + lane * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)yoff[i], 0, 2);
+        }
+        // the image is free once its read-out has reached the registers: request the next tile's residual into it
+        if constexpr (RES) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_res(t + 1);
+        }
+    }
+}
+
+// dispatch + launch of conv1x1_stream_kernel; MD_ERR_UNSUPPORTED_STREAM when the layer is not one it takes
+#define MD_ERR_UNSUPPORTED_STREAM 101
+static int g_stream_rounds = 1;   // workgroup rounds the pixel range is cut into (tools only: md_conv2d_set_stream_rounds)
+template <int K, int CB>
+static int launch_conv1x1_stream_t(ConvArgs &a, hipStream_t s) {
+    constexpr int NR = K == 512 ? 2 : (K == 128 ? 4 : 3);
+    constexpr int CT = 4 * CB * 32;
+    const int lds = NR * 32 * K * 2 + 4 * (32 * CB * 64) + CT * 4;
+    a.n_ctiles = a.Cout / CT;
+    a.n_ptiles = (a.M + 31) / 32;
+    const long long slots = 512LL * g_stream_rounds;                              // two resident workgroups per CU
+    long long tpw = ((long long)a.n_ptiles * a.n_ctiles + slots - 1) / slots;
+    if (tpw < 4) tpw = 4;
+    const long long n_chunks = (a.n_ptiles + tpw - 1) / tpw;
+    const long long chunks_per_xcd = (n_chunks + 7) / 8;
+    const long long blocks = chunks_per_xcd * 8 * a.n_ctiles;
+    if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
+    auto k = a.res ? (a.relu == 2 ? conv1x1_stream_kernel<K, CB, true, true> : conv1x1_stream_kernel<K, CB, false, true>)
+                   : (a.relu == 2 ? conv1x1_stream_kernel<K, CB, true, false> : conv1x1_stream_kernel<K, CB, false, false>);
+    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+    g_last_kernel = MD_CONV_KERNEL_STREAM_1X1;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, a, (int)tpw, (int)n_chunks, (int)chunks_per_xcd);
+    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
+}
+
+static bool stream1x1_takes(const ConvArgs &a) {
+    const bool cat_only = !a.adv || (a.os == 1 && a.oy == 0 && a.ox == 0 && a.Ho == a.Hf && a.Wo == a.Wf);
+    if (!a.pointwise || !cat_only || a.res_up || a.Kpad != a.Cin || a.x_bytes == 0) return false;
+    if (a.Cin != 128 && a.Cin != 256 && a.Cin != 512) return false;
+    return a.Cout % 128 == 0;
+}
+
+static int launch_conv1x1_stream(ConvArgs &a, hipStream_t s) {
+    if (!stream1x1_takes(a)) return MD_ERR_UNSUPPORTED_STREAM;
+    const bool wide = a.Cout % 256 == 0;
+    if (a.Cin == 128) return wide ? launch_conv1x1_stream_t<128, 2>(a, s) : launch_conv1x1_stream_t<128, 1>(a, s);
+    if (a.Cin == 256) return wide ? launch_conv1x1_stream_t<256, 2>(a, s) : launch_conv1x1_stream_t<256, 1>(a, s);
+    return launch_conv1x1_stream_t<512, 1>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1219,6 +1459,12 @@ extern "C" long long md_conv2d_set_chunk_limit(long long bytes) {
     return old;
 }
 
+extern "C" int md_conv2d_set_stream_rounds(int rounds) {   // tools only: workgroup rounds of conv1x1_stream_kernel (default 1)
+    const int old = g_stream_rounds;
+    g_stream_rounds = rounds >= 1 && rounds <= 64 ? rounds : 1;
+    return old;
+}
+
 extern "C" int md_conv2d_cout_tile(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 
 struct HeadArgs {   // the fused RPN head: y2 has 16 channels, y is not written
@@ -1359,6 +1605,17 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     a.w_bytes = (unsigned)(dma_ok ? w_bytes : 0);
     if (!dma_ok) variant = 1;
     if (a.korder != 0 && (a.korder != 1 || variant == 1 || a.Cin % 64 || a.kh * a.kw > 32)) return MD_ERR_ARG;
+    // weight-stationary streaming kernel for pointwise layers with K <= 512 (variant 30 forces it where it applies)
+    // auto: where it measured faster than the 128x128 kernel (r02 tools/conv_ab_stream.py, batch 60: 256->1024 + residual +43 %,
+    // 256->256 +25 %, 128->512 + residual +15 %, 512->256 +10 %, 512->2048 + residual +2 %; the 128-cout forms lose 2-15 %) and every
+    // workgroup gets at least 8 tiles to stream past the weights it loaded
+    const bool stream_auto = variant == 0 && !head && dma_ok && stream1x1_takes(a) && a.Cout % 256 == 0 &&
+                             (M + 31) / 32 * (a.Cout / (a.Cin == 512 ? 128 : 256)) >= 4096;
+    if ((variant == 30 || stream_auto) && !head) {
+        const int rc = dma_ok ? launch_conv1x1_stream(a, s) : MD_ERR_UNSUPPORTED_STREAM;
+        if (rc != MD_ERR_UNSUPPORTED_STREAM) return rc;
+        variant = 0;
+    }
     const bool fast = a.Cin % 64 == 0 && a.kh * a.kw <= 32;  // MODE 2 preconditions (then Kpad == Kreal)
     // 3x3 / stride 1 / pad 1 with korder-1 weights: halo-reuse kernel (variant 0 auto or 11 forced)
     const bool halo_ok = dma_ok && !a.adv && a.korder == 1 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 &&

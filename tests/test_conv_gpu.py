@@ -504,3 +504,82 @@ def test_conv1x1_dual_argument_checks():
     assert nn_ops.pack_dual(pc3, p3x3) is None                       # only 1x1 downsample convs
     p64 = nn_ops.pack_conv(torch.randn((64, 64, 1, 1)) * 0.1, relu=True).to(DEV)
     assert nn_ops.pack_dual(p64, nn_ops.pack_conv(torch.randn((64, 64, 1, 1)) * 0.1).to(DEV)) is None   # Cout <= 64: other tile shape
+
+
+@pytest.mark.parametrize("cfg", [
+    # name, N, H, W, Cin, Cout, act, residual, x buffer channels / offset, residual buffer channels / offset, output offset
+    ("k256_c1024_res", 2, 50, 84, 256, 1024, "relu", True, 0, 0, 0, 0, 0),
+    ("k128_c512_res_ragged", 3, 33, 37, 128, 512, "relu", True, 0, 0, 0, 0, 0),
+    ("k512_c2048_res", 1, 25, 42, 512, 2048, "relu", True, 0, 0, 0, 0, 0),
+    ("k512_c128_plain", 2, 29, 31, 512, 128, "relu", False, 0, 0, 0, 0, 0),
+    ("k256_c128_none", 1, 17, 19, 256, 128, "none", False, 0, 0, 0, 0, 0),
+    ("k256_c256_none_res", 1, 40, 40, 256, 256, "none", True, 0, 0, 0, 0, 0),
+    ("k128_c128_silu_slices", 2, 40, 40, 128, 128, "silu", True, 320, 64, 256, 128, 128),
+    ("k256_c512_silu_slices", 1, 23, 45, 256, 512, "silu", True, 512, 256, 1024, 512, 64),
+    ("k128_c384_relu", 1, 21, 20, 128, 384, "relu", False, 0, 0, 0, 0, 0),
+    ("tiny_one_tile", 1, 3, 5, 256, 256, "relu", True, 0, 0, 0, 0, 0),
+    ("one_pixel_more_than_a_tile", 1, 1, 33, 128, 256, "relu", True, 0, 0, 0, 0, 0),
+], ids=lambda c: c[0])
+def test_conv1x1_stream_kernel_is_bit_identical_to_the_tile_kernel(cfg):
+    """conv1x1_stream_kernel (variant 30: weights in registers, activations / residual streamed) against conv_igemm_kernel
+    (variant 20) on the same operands: same K order inside every MFMA chain and the same rounding points -> bit for bit;
+    ragged last tiles, channel-slice inputs / residuals, concat outputs, all three activations; and against torch fp32."""
+    from minddet_amd import _lib, nn_ops
+
+    name, N, H, W, Cin, Cout, act, use_res, xc, xo, rc, ro, co = cfg
+    g = torch.Generator().manual_seed(len(name) * 7 + Cin)
+    wt = torch.randn((Cout, Cin, 1, 1), generator=g) * (2.0 / Cin) ** 0.5
+    pc = nn_ops.pack_conv(wt, bias=torch.randn((Cout,), generator=g) * 0.1, relu={"none": 0, "relu": 1, "silu": "silu"}[act]).to(DEV)
+    xbuf = torch.randn((N, H, W, xc or Cin), generator=g).to(torch.bfloat16).to(DEV)
+    rbuf = torch.randn((N, H, W, rc or Cout), generator=g).to(torch.bfloat16).to(DEV) if use_res else None
+    kw = dict(x_c_off=xo if xc else None, res_c_off=ro if (rc and use_res) else None)
+    last = _lib.lib().md_conv2d_last_kernel
+    ref = nn_ops.conv2d(xbuf, pc, residual=rbuf, variant=20, **kw)
+    assert last() != 8
+    got = nn_ops.conv2d(xbuf, pc, residual=rbuf, variant=30, **kw)
+    assert last() == 8, "variant 30 did not reach conv1x1_stream_kernel"
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    cat = torch.full((N, H, W, co + Cout + 8), 3.0, dtype=torch.bfloat16, device=DEV)
+    kw_cat = dict(kw, res_c_off=(ro if rc else 0) if use_res else None)   # a concat output takes its residual as a channel slice
+    nn_ops.conv2d(xbuf, pc, residual=rbuf, variant=30, out=cat, c_off=co, **kw_cat)
+    assert last() == 8
+    assert torch.equal(cat[..., co:co + Cout], ref) and (cat[..., co + Cout:] == 3.0).all() and (cat[..., :co] == 3.0).all()
+    x_c = xbuf[..., xo:xo + Cin].float().cpu()
+    y = F.conv2d(x_c.permute(0, 3, 1, 2), wt.to(torch.bfloat16).float(), pc.bias[:Cout].float().cpu()).permute(0, 2, 3, 1)
+    y = F.silu(y) if act == "silu" else y
+    if use_res:
+        r_c = rbuf[..., ro:ro + Cout].float().cpu()
+        y = y.to(torch.bfloat16).float() + r_c
+    y = torch.relu(y) if act == "relu" else y
+    assert ((ref.float().cpu() - y).abs() <= 2e-2 * y.abs() + 2e-2).all()
+
+
+def test_conv1x1_stream_kernel_many_tiles_per_workgroup_and_rounds():
+    """A layer long enough that every workgroup streams many tiles (ring wrap-around, residual look-ahead), with 1 and 3
+    workgroup rounds; layers the kernel does not take fall back to the dispatcher's choice under variant 30."""
+    from minddet_amd import _lib, nn_ops
+
+    g = torch.Generator().manual_seed(5)
+    lib = _lib.lib()
+    for (Cin, Cout) in ((256, 1024), (128, 512), (512, 256)):
+        wt = torch.randn((Cout, Cin, 1, 1), generator=g) * (2.0 / Cin) ** 0.5
+        pc = nn_ops.pack_conv(wt, bias=torch.randn((Cout,), generator=g) * 0.1, relu=True).to(DEV)
+        x = torch.randn((6, 100, 167, Cin), generator=g).to(torch.bfloat16).to(DEV)
+        r = torch.randn((6, 100, 167, Cout), generator=g).to(torch.bfloat16).to(DEV)
+        ref = nn_ops.conv2d(x, pc, residual=r, variant=20)
+        for rounds in (1, 3):
+            old = lib.md_conv2d_set_stream_rounds(rounds)
+            try:
+                got = nn_ops.conv2d(x, pc, residual=r, variant=30)
+            finally:
+                lib.md_conv2d_set_stream_rounds(old)
+            assert lib.md_conv2d_last_kernel() == 8
+            assert torch.equal(got, ref), (Cin, Cout, rounds)
+    # not pointwise / K = 64 / Cout not a multiple of 128: variant 30 is the dispatcher's own choice
+    for (Cin, Cout, k) in ((64, 256, 1), (256, 64, 1), (128, 128, 3)):
+        wt = torch.randn((Cout, Cin, k, k), generator=g) * 0.05
+        pc = nn_ops.pack_conv(wt, pad=k // 2, relu=True).to(DEV)
+        x = torch.randn((1, 20, 24, Cin), generator=g).to(torch.bfloat16).to(DEV)
+        assert torch.equal(nn_ops.conv2d(x, pc, variant=30), nn_ops.conv2d(x, pc, variant=0))
+        assert lib.md_conv2d_last_kernel() != 8
