@@ -275,7 +275,7 @@ def main(argv=None):
     orig_conv2d = nn_ops.conv2d
     last_kernel = _lib.lib().md_conv2d_last_kernel
     KNAMES = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<128x128>", 3: "conv_igemm_kernel<small cout>",
-              4: "conv_igemm_kernel<generic K>", 5: "conv3x3_halo_kernel", 6: "conv variant", 7: "bottleneck_fused_kernel"}
+              4: "conv_igemm_kernel<generic K>", 5: "conv3x3_halo_kernel", 6: "conv variant", 7: "bottleneck_fused_kernel", 8: "conv1x1_stream_kernel"}
 
     bracket = {"calls": None, "idx": 0}    # calls: None = bracket every launch, else the per-step call indices to bracket
 
@@ -466,7 +466,7 @@ def main(argv=None):
         t_roof_ms = sum(max(r[2] / (PEAK_BF16_TFLOPS * 1e12), r[6] / PEAK_HBM_BPS) for r in all_recs) * 1e3
         traffic = all_traffic = None
         tp = os.path.join(ROOT, "profiles", "r02_conv_traffic.json")
-        PMC_PREFIX = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<256, 2, 2, 2, 2, 2,", 7: "bottleneck64_kernel"}  # all instantiations of the kernel
+        PMC_PREFIX = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<256, 2, 2, 2, 2, 2,", 7: "bottleneck64_kernel", 8: "conv1x1_stream_kernel"}  # all instantiations of the kernel
         if os.path.exists(tp):  # PMC passes are separate rocprofv3 runs (tools/pmc_traffic.py); same config only
             tj = json.load(open(tp))
             if tj.get("batch_per_gpu") == B and type(model).__name__ == "FasterRCNN":

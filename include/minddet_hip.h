@@ -229,6 +229,9 @@ long long md_conv2d_set_chunk_limit(long long bytes);
 /* Tools only: the number of workgroup rounds conv1x1_stream_kernel cuts a layer's pixel range into (default 1 = one resident
  * workgroup per slot streams its whole share).  Returns the previous value. */
 int md_conv2d_set_stream_rounds(int rounds);
+/* Tools only: workgroups per CU the grid of conv1x1_stream_kernel is sized for (default 2) and its cache-policy bits
+ * (1 = activation DMA nt, 2 = residual DMA nt, 4 = stores nt; default 6). */
+int md_conv2d_set_stream_tune(int wgs_per_cu, int cache_bits);
 
 /* ------------------------------------------------------------------------------------------
  * Streaming NHWC bf16 helpers between convs

@@ -86,6 +86,7 @@ struct ConvArgs {
     const uint16_t *x2;
     unsigned x2_bytes;
     int H2, W2, Xs2, stride2, nk_a;
+    int tune;               // conv1x1_stream_kernel cache-policy bits (tools: md_conv2d_set_stream_tune): 1 = x DMA nt, 2 = residual DMA nt, 4 = stores nt
     int Rs;                 // 0: the residual has the output's layout; > 0: residual pixel m, channel c at m*Rs + c (a channel
                             // slice of a wider [N,Ho,Wo,Rs] tensor, a.res pointing at its first channel)
 };
@@ -577,7 +578,9 @@ static int launch_conv_dual(ConvArgs &a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------
 #define MD_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
-template <int K, int CB, bool SILU, bool RES>
+// RES 0: no residual; 1: residual with the output's layout (or a channel slice, a.Rs); 2: residual [N, ceil(Ho/2), ceil(Wo/2), Cout] read with
+// nearest 2x upsampling (a.res_up: the FPN top-down add fused into the lateral conv)
+template <int K, int CB, bool SILU, int RES>
 __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int tpw, int n_chunks, int chunks_per_xcd) {
     typedef __attribute__((address_space(3))) void lds_void;
     constexpr int KS = K / 16, RB = K * 2;          // MFMA k-steps, bytes per activation row
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
     constexpr int EW = PT * EROW, NE = EW / 1024;   // image bytes; 1-KiB pieces = residual DMAs = store instructions per tile
     constexpr int RPE = 1024 / EROW;                // image rows per piece
     constexpr int ESH = CPP == 8 ? 1 : 2;           // image swizzle: chunk ^= (row >> ESH) & (CPP - 1)
-    constexpr int NRES = RES ? NE : 0;
+    constexpr int NRES = RES != 0 ? NE : 0;
     static_assert(K % 128 == 0 && K <= 512 && CB * K <= 512, "weights must fit 128 registers per lane");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;
@@ -655,21 +658,58 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
     auto dma_x = [&](int t, int slot) {
         __amdgpu_buffer_rsrc_t rs = x_desc(t);
         char *dst = ring + slot * SLOT;
+        if (a.tune & 1) {
 #pragma unroll
-        for (int i = 0; i < ND; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(dst + xdst[i]), 16, (int)xoff[i], 0, 0, 0);
+            for (int i = 0; i < ND; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(dst + xdst[i]), 16, (int)xoff[i], 0, 0, 2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < ND; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(dst + xdst[i]), 16, (int)xoff[i], 0, 0, 0);
+        }
+    };
+    // RES 2: per-lane (n, ho, wo) of the lane's NE image rows, advanced by one tile (32 pixels) per request
+    int u_wo[RES == 2 ? NE : 1], u_ho[RES == 2 ? NE : 1], u_n[RES == 2 ? NE : 1], u_m[RES == 2 ? NE : 1];
+    const int Hr = (a.Ho + 1) >> 1, Wr = (a.Wo + 1) >> 1;
+    if constexpr (RES == 2) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int m = t0 * PT + i * RPE + lane / CPP;
+            const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
+            u_m[i] = m; u_n[i] = n; u_ho[i] = r / a.Wo; u_wo[i] = r - u_ho[i] * a.Wo;
+        }
+    }
+    auto dma_res_up = [&](bool live) {   // requests the residual rows of the NEXT tile in sequence (tiles are consecutive)
+        const long long tot = (long long)a.N * Hr * Wr * a.Cout * 2;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.res, 0, live ? clip(tot) : 0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int lc = (lane % CPP) ^ (((i * RPE + lane / CPP) >> ESH) & (CPP - 1));
+            const unsigned off = u_m[i] < a.M ? (unsigned)((((u_n[i] * Hr + (u_ho[i] >> 1)) * Wr + (u_wo[i] >> 1)) * a.Cout + cout_w) * 2 + lc * 16)
+                                              : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(E + i * 1024), 16, (int)off, 0, 0, 0);
+            u_m[i] += PT; u_wo[i] += PT;
+            while (u_wo[i] >= a.Wo) { u_wo[i] -= a.Wo; if (++u_ho[i] == a.Ho) { u_ho[i] = 0; ++u_n[i]; } }
+        }
     };
     auto dma_res = [&](int t) {
+        if constexpr (RES == 2) { dma_res_up(t < nt); return; }
         __amdgpu_buffer_rsrc_t rs = r_desc(t);
+        if (a.tune & 2) {
 #pragma unroll
-        for (int i = 0; i < NE; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(E + i * 1024), 16, (int)roff[i], 0, 0, 2);
+            for (int i = 0; i < NE; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(E + i * 1024), 16, (int)roff[i], 0, 0, 2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NE; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(E + i * 1024), 16, (int)roff[i], 0, 0, 0);
+        }
     };
 
     // ---- prologue: the first D activation tiles and the first residual tile are requested BEFORE the weights
 #pragma unroll
     for (int t = 0; t < D; ++t) dma_x(t, t);
-    if constexpr (RES) dma_res(0);
+    if constexpr (RES != 0) dma_res(0);
     if (tid < 4 * CW) bias_lds[tid] = a.bias[ct * (4 * CW) + tid];
     bf16x8 wr[CB][KS];
 #pragma unroll
@@ -712,7 +752,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
         // s_waitcnt vmcnt(0) in front of an LDS access WITHOUT type-based alias info while LDS-DMAs are pending (seen with
         // float4 / uint2: it drained the x look-ahead every tile); the counted waits here are the synchronisation.
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (RES) MD_WAIT_VMCNT(ND);
+        if constexpr (RES != 0) MD_WAIT_VMCNT(ND);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < CB; ++b)
@@ -726,7 +766,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
                 pk.x = pk_bf16(s01.x, s01.y);
                 pk.y = pk_bf16(s23.x, s23.y);
                 u32x2 *cell = reinterpret_cast<u32x2 *>(E + lr * EROW + (((4 * b + g) ^ eswz) << 4) + 8 * lh);
-                if constexpr (RES) {
+                if constexpr (RES != 0) {
                     const u32x2 rv = *cell;
                     const f32x2 a01 = (f32x2){__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u)} +
                                       (f32x2){__uint_as_float(rv.x << 16), __uint_as_float(rv.x & 0xffff0000u)};
@@ -742,10 +782,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const u32x4 v = *reinterpret_cast<const u32x4 *>(E + i * 1024 + lane * 16);
-            __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)yoff[i], 0, 2);
+            if (a.tune & 4) __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)yoff[i], 0, 2);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)yoff[i], 0, 0);
         }
         // the image is free once its read-out has reached the registers: request the next tile's residual into it
-        if constexpr (RES) {
+        if constexpr (RES != 0) {
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             dma_res(t + 1);
@@ -756,6 +797,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
 // dispatch + launch of conv1x1_stream_kernel; MD_ERR_UNSUPPORTED_STREAM when the layer is not one it takes
 #define MD_ERR_UNSUPPORTED_STREAM 101
 static int g_stream_rounds = 1;   // workgroup rounds the pixel range is cut into (tools only: md_conv2d_set_stream_rounds)
+static int g_stream_wgs_per_cu = 2, g_stream_tune = 6;   // tools only: md_conv2d_set_stream_tune
 template <int K, int CB>
 static int launch_conv1x1_stream_t(ConvArgs &a, hipStream_t s) {
     constexpr int NR = K == 512 ? 2 : (K == 128 ? 4 : 3);
@@ -763,15 +805,17 @@ static int launch_conv1x1_stream_t(ConvArgs &a, hipStream_t s) {
     const int lds = NR * 32 * K * 2 + 4 * (32 * CB * 64) + CT * 4;
     a.n_ctiles = a.Cout / CT;
     a.n_ptiles = (a.M + 31) / 32;
-    const long long slots = 512LL * g_stream_rounds;                              // two resident workgroups per CU
+    const long long slots = 256LL * g_stream_wgs_per_cu * g_stream_rounds;        // resident workgroups (two per CU)
+    a.tune = g_stream_tune;
     long long tpw = ((long long)a.n_ptiles * a.n_ctiles + slots - 1) / slots;
     if (tpw < 4) tpw = 4;
     const long long n_chunks = (a.n_ptiles + tpw - 1) / tpw;
     const long long chunks_per_xcd = (n_chunks + 7) / 8;
     const long long blocks = chunks_per_xcd * 8 * a.n_ctiles;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
-    auto k = a.res ? (a.relu == 2 ? conv1x1_stream_kernel<K, CB, true, true> : conv1x1_stream_kernel<K, CB, false, true>)
-                   : (a.relu == 2 ? conv1x1_stream_kernel<K, CB, true, false> : conv1x1_stream_kernel<K, CB, false, false>);
+    auto k = a.res ? (a.relu == 2 ? conv1x1_stream_kernel<K, CB, true, 1> : conv1x1_stream_kernel<K, CB, false, 1>)
+                   : (a.relu == 2 ? conv1x1_stream_kernel<K, CB, true, 0> : conv1x1_stream_kernel<K, CB, false, 0>);
+    if (a.res_up) k = conv1x1_stream_kernel<K, CB, false, 2>;
     if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
     g_last_kernel = MD_CONV_KERNEL_STREAM_1X1;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, a, (int)tpw, (int)n_chunks, (int)chunks_per_xcd);
@@ -780,7 +824,9 @@ static int launch_conv1x1_stream_t(ConvArgs &a, hipStream_t s) {
 
 static bool stream1x1_takes(const ConvArgs &a) {
     const bool cat_only = !a.adv || (a.os == 1 && a.oy == 0 && a.ox == 0 && a.Ho == a.Hf && a.Wo == a.Wf);
-    if (!a.pointwise || !cat_only || a.res_up || a.Kpad != a.Cin || a.x_bytes == 0) return false;
+    if (!a.pointwise || !cat_only || a.Kpad != a.Cin || a.x_bytes == 0) return false;
+    // upsampled residual (the FPN lateral convs): plain output, no SiLU, residual tensor inside the 32-bit offset reach
+    if (a.res_up && (a.adv || a.relu == 2 || (long long)a.N * ((a.Ho + 1) / 2) * ((a.Wo + 1) / 2) * a.Cout * 2 >= 0x7fff0000LL)) return false;
     if (a.Cin != 128 && a.Cin != 256 && a.Cin != 512) return false;
     return a.Cout % 128 == 0;
 }
@@ -1465,6 +1511,12 @@ extern "C" int md_conv2d_set_stream_rounds(int rounds) {   // tools only: workgr
     return old;
 }
 
+extern "C" int md_conv2d_set_stream_tune(int wgs_per_cu, int cache_bits) {   // tools only
+    g_stream_wgs_per_cu = wgs_per_cu >= 1 && wgs_per_cu <= 8 ? wgs_per_cu : 2;
+    g_stream_tune = cache_bits & 7;
+    return 0;
+}
+
 extern "C" int md_conv2d_cout_tile(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 
 struct HeadArgs {   // the fused RPN head: y2 has 16 channels, y is not written
@@ -1541,7 +1593,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     a.res_up = at->res_upsample != 0 && params[3] != nullptr;
     // one LDS staging buffer by default: measured r01 (tools/conv_ab.py), 4 resident workgroups per CU with a serial
     // DMA -> MFMA loop beat 2 double-buffered ones on every benchmark layer (+8...43 %); variant 2 keeps the double buffer
-    a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 25;
+    a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 25 || at->variant == 30 || at->variant == 31;
     a.stamp = 0; a.dbg = nullptr;
     if ((at->variant >= 17 && at->variant <= 19) || at->variant == 25) {
         // timing ablations / stamp builds: wrong results by construction, so not part of the product library
@@ -1596,7 +1648,8 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     hipStream_t s = (hipStream_t)stream;
     // variant: 0 = auto (cost model below); 1 = register-staged 128x128; 2 = LDS-DMA 128x128 with two staging buffers;
     // 11 = 128-cout halo kernel; 15 / 22 = ping-pong kernel (32x32x16 / 16x16x32 MFMA);
-    // 20 = LDS-DMA 128x128 with one staging buffer; 27 = 64-cout halo kernel; 17-19 / 25 = timing ablations / stamps, MD_DIAG
+    // 20 = LDS-DMA 128x128 with one staging buffer; 27 = 64-cout halo kernel; 30 = conv1x1_stream_kernel where it applies,
+    // 31 = auto without it; 17-19 / 25 = timing ablations / stamps, MD_DIAG
     // builds only (the product library answers MD_ERR_ARG)
     int variant = variant_override >= 0 ? variant_override : at->variant;
     const long long x_bytes = (long long)a.N * a.H * a.W * a.Xs * 2 - (at->x_cin > 0 ? at->x_c_off * 2 : 0), w_bytes = (long long)cout_pad * a.Kpad * 2;
@@ -1606,10 +1659,13 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     if (!dma_ok) variant = 1;
     if (a.korder != 0 && (a.korder != 1 || variant == 1 || a.Cin % 64 || a.kh * a.kw > 32)) return MD_ERR_ARG;
     // weight-stationary streaming kernel for pointwise layers with K <= 512 (variant 30 forces it where it applies)
-    // auto: where it measured faster than the 128x128 kernel (r02 tools/conv_ab_stream.py, batch 60: 256->1024 + residual +43 %,
-    // 256->256 +25 %, 128->512 + residual +15 %, 512->256 +10 %, 512->2048 + residual +2 %; the 128-cout forms lose 2-15 %) and every
-    // workgroup gets at least 8 tiles to stream past the weights it loaded
-    const bool stream_auto = variant == 0 && !head && dma_ok && stream1x1_takes(a) && a.Cout % 256 == 0 &&
+    // auto: where it measured faster than the 128x128 kernel INSIDE the Faster R-CNN step (r02 tools/stream_insitu_tune.py, batch 60;
+    // a replay loop on one layer flatters it: the activation tensor then survives in the Infinity Cache between launches):
+    // 256->1024 + residual -0.40 ms/step (5 launches), 512->256 -0.12, 512->2048 + residual -0.09; 128->512 + residual +0.15 (stays on
+    // the 128x128 kernel); the 128-cout forms lose 2-15 % -- and every workgroup gets at least 8 tiles to stream past its weights
+    const bool no_stream = variant == 31;   // 31 = the dispatcher's choice without conv1x1_stream_kernel (A/B)
+    if (no_stream) variant = 0;
+    const bool stream_auto = variant == 0 && !no_stream && !head && dma_ok && stream1x1_takes(a) && a.Cout % 256 == 0 && a.Cin != 128 &&
                              (M + 31) / 32 * (a.Cout / (a.Cin == 512 ? 128 : 256)) >= 4096;
     if ((variant == 30 || stream_auto) && !head) {
         const int rc = dma_ok ? launch_conv1x1_stream(a, s) : MD_ERR_UNSUPPORTED_STREAM;

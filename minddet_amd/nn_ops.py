@@ -94,7 +94,8 @@ def conv_out_hw(h, w, pc):
     return (h + 2 * pc.pad - pc.kh) // pc.stride + 1, (w + 2 * pc.pad - pc.kw) // pc.stride + 1
 
 
-CONV_VARIANT = 0  # 0 auto; 1/2/3 force a kernel variant (A/B measurements, see md_conv2d_attrs)
+import os as _os
+CONV_VARIANT = int(_os.environ.get("MD_CONV_VARIANT", "0"))  # 0 auto; other values force a kernel variant (A/B measurements, see md_conv2d_attrs; 31 = auto without conv1x1_stream_kernel)
 
 
 def conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0, res_upsample=False, x_c_off=None, res_c_off=None):

@@ -555,6 +555,28 @@ def test_conv1x1_stream_kernel_is_bit_identical_to_the_tile_kernel(cfg):
     assert ((ref.float().cpu() - y).abs() <= 2e-2 * y.abs() + 2e-2).all()
 
 
+@pytest.mark.parametrize("shape", [(2, 50, 84, 256, 256), (1, 25, 43, 512, 256), (3, 13, 21, 256, 512)], ids=str)
+def test_conv1x1_stream_kernel_upsampled_residual(shape):
+    """The FPN lateral conv with the top-down add fused (residual at half resolution, nearest 2x upsampling, odd sizes included):
+    stream kernel == tile kernel bit for bit, and == conv + upsample + add in torch."""
+    from minddet_amd import _lib, nn_ops
+
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(H * W)
+    wt = torch.randn((Cout, Cin, 1, 1), generator=g) * (2.0 / Cin) ** 0.5
+    pc = nn_ops.pack_conv(wt, bias=torch.randn((Cout,), generator=g) * 0.1, relu=False).to(DEV)
+    x = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16).to(DEV)
+    r = torch.randn((N, (H + 1) // 2, (W + 1) // 2, Cout), generator=g).to(torch.bfloat16).to(DEV)
+    ref = nn_ops.conv2d(x, pc, residual=r, res_upsample=True, variant=20)
+    got = nn_ops.conv2d(x, pc, residual=r, res_upsample=True, variant=30)
+    assert _lib.lib().md_conv2d_last_kernel() == 8
+    assert torch.equal(got, ref)
+    y = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wt.to(torch.bfloat16).float(), pc.bias[:Cout].float().cpu()).permute(0, 2, 3, 1)
+    up = r.float().cpu().repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)[:, :H, :W]
+    y = y.to(torch.bfloat16).float() + up
+    assert ((ref.float().cpu() - y).abs() <= 2e-2 * y.abs() + 2e-2).all()
+
+
 def test_conv1x1_stream_kernel_many_tiles_per_workgroup_and_rounds():
     """A layer long enough that every workgroup streams many tiles (ring wrap-around, residual look-ahead), with 1 and 3
     workgroup rounds; layers the kernel does not take fall back to the dispatcher's choice under variant 30."""
