@@ -25,6 +25,7 @@ The batch is resident in HBM in the model's input layout (zero-bordered 4-channe
 region; --from-uint8 also times md_image_preprocess from a resident uint8 batch.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -43,8 +44,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=60,
-                    help="images per GPU per step (r01, no instrumentation: 32 -> 1640, 48 -> 1797, 60 -> 1870, 128 -> 1893 images/s; 60 is the largest batch whose P2 tensors stay under the 2 GiB reach of one launch)")
+    ap.add_argument("--batch", type=int, default=120,
+                    help="images per GPU per step (r02 same-box, no instrumentation: 60 -> 2068, 90 -> 2090, 120 -> 2107 images/s; r01: 32 -> 1640, "
+                         "48 -> 1797, 60 -> 1870; above 60 the P2-level tensors pass 2 GiB and md_conv2d runs those layers as two image chunks)")
     ap.add_argument("--bracket", choices=["dominant", "all"], default="dominant",
                     help="which conv launches of the TIMED region are bracketed by HIP events: only the dominant kernel's (default: "
                          "the whole-set table then comes from the last warmup step, where every launch is bracketed; 2 events per "
@@ -274,6 +276,8 @@ def main(argv=None):
     records = []
     orig_conv2d = nn_ops.conv2d
     last_kernel = _lib.lib().md_conv2d_last_kernel
+    launch_count = _lib.lib().md_conv2d_launch_count   # a call on a batch past the 2 GiB chunk limit launches once per image chunk
+    launch_count.restype = ctypes.c_longlong
     KNAMES = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<128x128>", 3: "conv_igemm_kernel<small cout>",
               4: "conv_igemm_kernel<generic K>", 5: "conv3x3_halo_kernel", 6: "conv variant", 7: "bottleneck_fused_kernel", 8: "conv1x1_stream_kernel"}
 
@@ -288,6 +292,7 @@ def main(argv=None):
         if _skip():
             return orig_conv2d(x, pc, residual=residual, relu=relu, out=out, variant=variant, c_off=c_off, res_upsample=res_upsample, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        l0 = launch_count()
         e0.record()
         y = orig_conv2d(x, pc, residual=residual, relu=relu, out=out, variant=variant, c_off=c_off, res_upsample=res_upsample, **kw)
         e1.record()
@@ -296,7 +301,7 @@ def main(argv=None):
         res_elems = 0 if residual is None else (residual.numel() if res_upsample else n * ho * wo * pc.cout)
         byts = 2.0 * (x.shape[0] * x.shape[1] * x.shape[2] * pc.cin + n * ho * wo * pc.cout + pc.cout * pc.cin_real * pc.kh * pc.kw + res_elems)
         records.append((e0, e1, 2.0 * n * ho * wo * pc.cout * pc.cin_real * pc.kh * pc.kw, tuple(x.shape[:3]) + (pc.cin,), pc.cout, pc.kh, byts,
-                        last_kernel(), pc, None))
+                        last_kernel(), pc, None, launch_count() - l0))
         return y
 
     orig_conv2d_head = nn_ops.conv2d_head
@@ -305,13 +310,14 @@ def main(argv=None):
         if _skip():
             return orig_conv2d_head(x, pc, pc2, variant=variant)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        l0 = launch_count()
         e0.record()
         y = orig_conv2d_head(x, pc, pc2, variant=variant)
         e1.record()
         n, ho, wo, _ = y.shape
         fl = 2.0 * n * ho * wo * (pc.cout * pc.cin_real * pc.kh * pc.kw + pc2.cout * pc2.cin_real)
         byts = 2.0 * (x.numel() + y.numel() + pc.cout * pc.cin_real * pc.kh * pc.kw + pc2.cout * pc2.cin_real)
-        records.append((e0, e1, fl, tuple(x.shape), pc.cout, pc.kh, byts, last_kernel(), pc, pc2))
+        records.append((e0, e1, fl, tuple(x.shape), pc.cout, pc.kh, byts, last_kernel(), pc, pc2, launch_count() - l0))
         return y
 
     timed_extra = {}      # other instrumented entry points of nn_ops (name -> wrapper), e.g. the fused bottleneck block
@@ -322,11 +328,12 @@ def main(argv=None):
             if _skip():
                 return orig_bottleneck(x, blk, residual=residual, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            l0 = launch_count()
             e0.record()
             y = orig_bottleneck(x, blk, residual=residual, **kw)
             e1.record()
             fl, byts = blk.flops_bytes(x.shape[0], x.shape[1], x.shape[2], with_residual_tensor=residual is not None)
-            records.append((e0, e1, fl, tuple(x.shape), blk.cout, 3, byts, last_kernel(), None, None))
+            records.append((e0, e1, fl, tuple(x.shape), blk.cout, 3, byts, last_kernel(), None, None, launch_count() - l0))
             return y
 
         timed_extra["bottleneck"] = (orig_bottleneck, timed_bottleneck)
@@ -338,11 +345,12 @@ def main(argv=None):
             if _skip():
                 return orig_dual(xa, xb, pk, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            l0 = launch_count()
             e0.record()
             y = orig_dual(xa, xb, pk, **kw)
             e1.record()
             fl, byts = pk.flops_bytes(xa.shape[0], xa.shape[1], xa.shape[2])
-            records.append((e0, e1, fl, tuple(xa.shape[:3]) + (pk.ca + pk.cb,), pk.cout, 1, byts, last_kernel(), None, None))
+            records.append((e0, e1, fl, tuple(xa.shape[:3]) + (pk.ca + pk.cb,), pk.cout, 1, byts, last_kernel(), None, None, launch_count() - l0))
             return y
 
         timed_extra["conv1x1_dual"] = (orig_dual, timed_dual)
@@ -442,11 +450,12 @@ def main(argv=None):
         ms = [e0.elapsed_time(e1) for e0, e1, *_ in all_recs]
         tot_ms = sum(ms)
         tot_fl = sum(r[2] for r in all_recs)
+        n_all = sum(max(r[10], 1) for r in all_recs)   # kernel launches (a chunked call counts once per chunk)
         # per kernel; the DOMINANT one (most time) fills the contract fields, the whole conv/FC set goes to "all_conv"
         per_k = {}
         for r, t_ms in zip(all_recs, ms):
             d = per_k.setdefault(r[7], [0.0, 0.0, 0.0, 0])
-            d[0] += t_ms; d[1] += r[2]; d[2] += r[6]; d[3] += 1
+            d[0] += t_ms; d[1] += r[2]; d[2] += r[6]; d[3] += max(r[10], 1)
         dom = max(per_k, key=lambda k_: per_k[k_][0])
         dom_share = per_k[dom][0] / tot_ms
         # the dominant kernel's figures always come from the TIMED region's events
@@ -454,7 +463,7 @@ def main(argv=None):
         d_n = 0
         for r in records:
             if r[7] == dom:
-                d_ms += r[0].elapsed_time(r[1]); d_fl += r[2]; d_by += r[6]; d_n += 1
+                d_ms += r[0].elapsed_time(r[1]); d_fl += r[2]; d_by += r[6]; d_n += max(r[10], 1)   # kernel launches, not calls
         if d_n == 0:
             raise RuntimeError("bench: the dominant kernel of the bracketed warmup step was not launched in the timed region")
         # which roofline binds the dominant kernel's launches in aggregate: HBM (algorithmic bytes / 8 TB/s) or MFMA
@@ -493,9 +502,9 @@ def main(argv=None):
                                  "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                                  "frac_of_layerwise_roofline": round(t_roof_ms / tot_ms, 4),
                                  "traffic_mb_per_launch": all_traffic,
-                                 "algorithmic_mb_per_launch": round(sum(r[6] for r in all_recs) / len(all_recs) / 1e6, 2),
-                                 "launches_per_step": len(all_recs) // all_steps,
-                                 "avg_launch_us": round(tot_ms * 1e3 / len(all_recs), 2),
+                                 "algorithmic_mb_per_launch": round(sum(r[6] for r in all_recs) / n_all / 1e6, 2),
+                                 "launches_per_step": n_all // all_steps,
+                                 "avg_launch_us": round(tot_ms * 1e3 / n_all, 2),
                                  "conv_ms_per_step": round(tot_ms / all_steps, 3),
                                  "algorithmic_gflop_per_step": round(tot_fl / all_steps / 1e9, 1)}}
 
@@ -546,10 +555,10 @@ def main(argv=None):
     if args.dump_convs and rank == 0 and records:
         # per-layer table: measured time against the layer's own roofline max(flops / MFMA peak, algorithmic bytes / HBM peak)
         per = {}
-        for e0, e1, fl, xs, cout, k, byts, kid, *_pcs in records:
+        for e0, e1, fl, xs, cout, k, byts, kid, _pc, _pc2, n_l in records:
             key = f"{xs}->{cout} k{k}" + (" [block]" if kid == 7 else "")
             d = per.setdefault(key, [0.0, 0.0, 0, 0.0, kid])
-            d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += 1; d[3] += byts
+            d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += max(n_l, 1); d[3] += byts
         rows = []
         for k_, v in per.items():
             t_roof = max(v[1] / (PEAK_BF16_TFLOPS * 1e12), v[3] / PEAK_HBM_BPS) * 1e3

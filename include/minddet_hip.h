@@ -222,6 +222,10 @@ enum {
     MD_CONV_KERNEL_STREAM_1X1 = 8       /* conv1x1_stream_kernel: weight-stationary pointwise layers, K <= 512 */
 };
 int md_conv2d_last_kernel(void);
+/* Running count of the kernels the calling host thread's conv-family calls (md_conv2d, md_conv2d_head, md_conv1x1_dual,
+ * md_bottleneck) have launched: a call on a batch past the chunk limit launches once per image chunk.  Diagnostic only:
+ * bench.py divides a call's algorithmic work and bracketed time by its launches. */
+long long md_conv2d_launch_count(void);
 /* md_conv2d runs a batch whose activation tensor exceeds `bytes` (default and maximum: 2 GiB - 64 KiB, the reach of the
  * kernels' 32-bit LDS-DMA offsets) as consecutive image chunks on the same stream.  Returns the previous limit; tests
  * lower it to exercise the chunked path on small tensors. */

@@ -495,8 +495,8 @@ extern "C" int md_bottleneck(MD_AOT_ARGS) {
         a.dbg = g_bn_stamp_buf;
 #endif
         hipLaunchKernelGGL(k, dim3((unsigned)(a.pt_per_xcd * 8)), dim3(512), BN_LDS, (hipStream_t)stream, a);
+        md_note_conv_kernel(MD_CONV_KERNEL_BOTTLENECK);
     }
-    md_note_conv_kernel(MD_CONV_KERNEL_BOTTLENECK);
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }

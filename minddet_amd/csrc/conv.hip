@@ -127,6 +127,8 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((c
 // id of the kernel the dispatcher chose for this host thread's last md_conv2d call (md_conv2d_last_kernel): lets a
 // profiler-less caller (bench.py) attribute per-launch timings to kernels
 static thread_local int g_last_kernel = 0;
+// kernels launched so far by this host thread's conv-family calls (md_conv2d_launch_count): a call on a batch past the chunk limit launches once per image chunk
+static thread_local long long g_launch_count = 0;
 // activation bytes above which md_conv2d slices the batch (the kernels' 32-bit DMA offsets); lowered only by tests
 static long long g_chunk_limit = 0x7fff0000LL;
 
@@ -509,6 +511,7 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
     const bool cat_only = a.adv && a.os == 1 && !a.oy && !a.ox && a.Ho == a.Hf && a.Wo == a.Wf;
     const bool plain = MODE == 2 && (!a.adv || cat_only) && !a.res_up;
     constexpr int CT = WC * FC * 32, PT = WP * FP * 32;
+    ++g_launch_count;
     g_last_kernel = MODE == 1 ? MD_CONV_KERNEL_IGEMM_GENERIC_K : (CT == 128 && PT == 128 ? MD_CONV_KERNEL_IGEMM_128 :
                     (CT < 128 ? MD_CONV_KERNEL_IGEMM_SMALL_COUT : MD_CONV_KERNEL_OTHER));
     a.n_ctiles = (a.Cout + CT - 1) / CT;
@@ -539,6 +542,7 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
 // 128 x 128 single-buffer kernel on the K-concatenation of two inputs (md_conv1x1_dual)
 static int launch_conv_dual(ConvArgs &a, hipStream_t s) {
     constexpr int CT = 128, PT = 128;
+    ++g_launch_count;
     g_last_kernel = MD_CONV_KERNEL_IGEMM_128;
     a.n_ctiles = (a.Cout + CT - 1) / CT;
     a.n_ptiles = (a.M + PT - 1) / PT;
@@ -817,6 +821,7 @@ static int launch_conv1x1_stream_t(ConvArgs &a, hipStream_t s) {
                    : (a.relu == 2 ? conv1x1_stream_kernel<K, CB, true, 0> : conv1x1_stream_kernel<K, CB, false, 0>);
     if (a.res_up) k = conv1x1_stream_kernel<K, CB, false, 2>;
     if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+    ++g_launch_count;
     g_last_kernel = MD_CONV_KERNEL_STREAM_1X1;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, a, (int)tpw, (int)n_chunks, (int)chunks_per_xcd);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
@@ -1041,6 +1046,7 @@ __global__ __launch_bounds__(256, CT == 64 ? 4 : 2) void conv3x3_halo_kernel(Con
 
 template <int CT, bool ONE_HALO>
 static int launch_conv3x3_halo(ConvArgs &a, hipStream_t s) {
+    ++g_launch_count;
     g_last_kernel = MD_CONV_KERNEL_HALO;
     const int tiles_x = (a.W + HT_W - 1) / HT_W, tiles_y = (a.H + HT_H - 1) / HT_H;
     a.n_ctiles = (a.Cout + CT - 1) / CT;
@@ -1459,6 +1465,7 @@ static int launch_conv_pingpong_head_mf(ConvArgs &a, hipStream_t s, long long bl
 }
 
 static int launch_conv_pingpong_head(ConvArgs &a, hipStream_t s) {
+    ++g_launch_count;
     g_last_kernel = MD_CONV_KERNEL_PINGPONG;
     a.n_ctiles = 1;
     a.n_ptiles = (a.M + 255) / 256;
@@ -1471,6 +1478,7 @@ static int launch_conv_pingpong_head(ConvArgs &a, hipStream_t s) {
 
 template <int ABL = 0, int MF = 0>
 static int launch_conv_pingpong(ConvArgs &a, hipStream_t s) {
+    ++g_launch_count;
     g_last_kernel = MD_CONV_KERNEL_PINGPONG;
     a.n_ctiles = a.Cout / 256;
     a.n_ptiles = (a.M + 255) / 256;
@@ -1495,8 +1503,9 @@ using namespace md;
 // Required weight padding for a given Cout (the tile the dispatcher will pick): exported so the
 // host packer pads consistently.
 extern "C" int md_conv2d_last_kernel(void) { return g_last_kernel; }
+extern "C" long long md_conv2d_launch_count(void) { return g_launch_count; }
 namespace md {
-void md_note_conv_kernel(int id) { g_last_kernel = id; }
+void md_note_conv_kernel(int id) { g_last_kernel = id; ++g_launch_count; }
 long long md_chunk_limit() { return g_chunk_limit; }
 }
 extern "C" long long md_conv2d_set_chunk_limit(long long bytes) {
