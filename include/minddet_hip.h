@@ -194,19 +194,6 @@ int md_conv1x1_dual(MD_AOT_ARGS);
  * extra: md_conv2d_attrs of the FIRST conv (relu must be 1, plain addressing). */
 int md_conv2d_head(MD_AOT_ARGS);
 
-/* conv (256 output channels, ReLU: a layer of the 256x256 ping-pong kernel) followed by a 1x1 EXPAND conv + residual + ReLU in ONE
- * launch where the fused kernel applies (Cout3 % 256 == 0, >= 64 pixel tiles): the second half of a ResNet bottleneck block with 256
- * mid channels (centernet/src/resnet.py:139-178: relu(bn2(conv2(.))) -> bn3(conv3(.)) + identity -> relu).  The 256-channel
- * intermediate stays in LDS, and the HBM-bound expand conv's residual reads / stores run under other workgroups' MFMA-bound 3x3
- * loops.  Elsewhere the two convolutions run back to back through a temporary; results are bit-identical either way (same MFMA
- * k-order, bf16 rounding after each conv and after the residual add).
- * in : x[N,H,W,Cin] bf16, w[256,Kpad] bf16, bias[256] f32 (as md_conv2d), w3[Cout3_pad,256] bf16, b3[Cout3_pad] f32 (a packed 1x1 conv),
- *      w3f[Cout3/32,16,64,8] bf16 | NULL = w3 in MFMA-fragment order, element (cb, s, lane, e) = w3[32 cb + lane % 32][16 s + 8 (lane / 32) + e]
- *      (the fused kernel loads its A operands straight from it, 1 KiB contiguous per wave instruction; NULL: always two launches),
- *      residual[N,Ho,Wo,Cout3] bf16 | NULL ; out: y[N,Ho,Wo,Cout3] bf16 ; optional workspace (>= N*Ho*Wo*512 bytes) for the fallback.
- * extra: md_conv2d_attrs of the first conv (relu = 1; no adv / channel-slice / upsampled residual; variant 31 forces the fallback). */
-int md_conv2d_expand(MD_AOT_ARGS);
-
 /* A whole ResNet bottleneck block (centernet/src/resnet.py:139-178: conv1 1x1 + bn + relu -> conv2 3x3 + bn + relu -> conv3 1x1 +
  * bn, + residual, relu) with 64 mid channels, stride 1 and 256 output channels in ONE launch: both 64-channel intermediates stay
  * in LDS and x is read from HBM once (1024 B of HBM traffic per pixel instead of 2048 B for the three md_conv2d launches, which are
@@ -249,9 +236,6 @@ int md_conv2d_set_stream_rounds(int rounds);
 /* Tools only: workgroups per CU the grid of conv1x1_stream_kernel is sized for (default 2) and its cache-policy bits
  * (1 = activation DMA nt, 2 = residual DMA nt, 4 = stores nt; default 6). */
 int md_conv2d_set_stream_tune(int wgs_per_cu, int cache_bits);
-/* Tools only: the per-wave start delay step of md_conv2d_expand's fused tail, in s_sleep(8) units (wave w waits ((w / 4) * 4 + w % 4)
- * steps once per tile, so that the waves' MFMA and output phases overlap; default 2).  Returns the previous value. */
-int md_conv2d_set_expand_stagger(int units);
 
 /* ------------------------------------------------------------------------------------------
  * Streaming NHWC bf16 helpers between convs

@@ -74,8 +74,6 @@ struct ConvArgs {
     const uint16_t *w2;     // fused 1x1 head (conv_pingpong_kernel<.., HEAD>): [>=16][256] bf16, K = the conv's 256 output channels
     const float *b2;        // [>=16] fp32
     uint16_t *y2;           // [N,Ho,Wo,16] bf16 -- the ONLY tensor a HEAD launch writes
-    const uint16_t *res2;   // fused 1x1 expand (conv_pingpong_kernel<.., TAIL 2>): w2 = [cout2 / 32][16][64][8] bf16 (fragment-major), b2 = [cout2] fp32, res2 = residual
-    int cout2;              // [N,Ho,Wo,cout2] bf16 | null, y2 = [N,Ho,Wo,cout2] bf16 (cout2 % 256 == 0) -- the ONLY tensor such a launch writes
     int pointwise;          // 1x1 / stride 1 / pad 0 (input pixel index == output pixel index)
     int bias_lds_off;       // byte offset of the CT-float bias copy in LDS (past the staging buffers and the epilogue image)
     int stamp;              // MD_DIAG builds only (variant 25): a mid-grid workgroup writes its cycle stamps to a.dbg
@@ -804,7 +802,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
 #define MD_ERR_UNSUPPORTED_STREAM 101
 static int g_stream_rounds = 1;   // workgroup rounds the pixel range is cut into (tools only: md_conv2d_set_stream_rounds)
 static int g_stream_wgs_per_cu = 2, g_stream_tune = 6;   // tools only: md_conv2d_set_stream_tune
-static int g_expand_stagger = 2;   // md_conv2d_expand: per-wave start delay step of the fused tail, in s_sleep(8) units (tools: md_conv2d_set_expand_stagger)
 template <int K, int CB>
 static int launch_conv1x1_stream_t(ConvArgs &a, hipStream_t s) {
     constexpr int NR = K == 512 ? 2 : (K == 128 ? 4 : 3);
@@ -1092,10 +1089,8 @@ struct KWalk { int tap, kh, kw, cc0; };
 
 // MF 0: v_mfma_f32_32x32x16_bf16, MF 1: v_mfma_f32_16x16x32_bf16 (same LDS image, reads and cycles per flop; the chip holds a
 // different clock on the two shapes under load -- MI355X_MICROARCH.md DVFS item 7 -- so both are built and the faster kept).
-// TAIL 1: fused 1x1 head (<= 16 channels); TAIL 2: fused 1x1 EXPAND conv (+ residual + ReLU) out of the epilogue image, see below
-template <int ABL, int MF = 0, int GEN = 1, int TAIL = 0>  // GEN as in conv_igemm_kernel; ABL 0: product; timing ablations (wrong results): 1 no in-loop staging, 2 no output stores, 4 stamps
+template <int ABL, int MF = 0, int GEN = 1, bool HEAD = false>  // GEN as in conv_igemm_kernel; HEAD: fused 1x1 head; ABL 0: product; timing ablations (wrong results): 1 no in-loop staging, 2 no output stores, 4 stamps
 __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
-    constexpr bool HEAD = TAIL == 1;
     constexpr int CT = 256, PT = 256, NT = 512;
     constexpr int EP_STRIDE = CT * 2 + 16;
     constexpr unsigned OOR = 0x80000000u;
@@ -1373,132 +1368,6 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         }
     }
     __syncthreads();
-    if constexpr (TAIL == 2) {
-        // ---- fused 1x1 expand conv: y2[p][c] = relu(b2[c] + sum_k W2[c][k] * T2[p][k] + res2[p][c]), K = 256 straight from the
-        // epilogue image T2 = relu(conv + bias) (bf16, as md_conv2d would have written it).  The second half of a ResNet
-        // bottleneck (centernet/src/resnet.py:139-178: conv2 3x3 -> conv3 1x1 + residual + relu) without the 256-channel round
-        // trip through HBM, and with the HBM-bound expand conv's residual reads / output stores running under OTHER workgroups'
-        // MFMA-bound 3x3 loops.  cout2 / 256 passes; in a pass wave (cg, pg) owns 64 output channels x 128 pixels (2 x 4
-        // accumulator tiles, the registers of the main loop): A fragments (W2 rows) come straight from L2 into registers through a
-        // ring of k-steps, B fragments are ds_read_b128 from the image (row stride 528 B: conflict-free).  No workgroup barrier from
-        // here on: each wave transposes its 32 x 32 blocks through a private 2.5-KiB slab (80-B rows), adds the residual (requested
-        // four blocks ahead) and stores 64-B runs.  Same MFMA k-order and rounding points as the unfused pair -> bit-identical.
-        const int cg = wave >> 1, pg = wave & 1;
-        char *slab = smem + PT * EP_STRIDE + CT * 4 + wave * 3456;
-        float *b2w = reinterpret_cast<float *>(slab + 2560);   // this wave's 64 biases of the pass
-        const int n_pass = a.cout2 / 256;
-        const int e_px = lane >> 2, e_ch = lane & 3;   // read-out lane map of a slab: pixel e_px (+16), 16-B chunk e_ch
-        constexpr bool has_res = true;   // the fused form always adds a residual (md_conv2d_expand runs a residual-free pair as two launches):
-                                         // straight-line passes, so that hipcc's waitcnt pass counts instead of draining the queue at joins
-        // every global access of the tail goes through a buffer descriptor (scalar base, ONE per-lane offset register each): the
-        // 64-bit per-lane pointers of a first version spilled, and the reload in front of every pass waited for the residual loads.
-        // Residual / output descriptors start at the tile's first pixel and end with the tensor: rows past M read 0 / are not stored.
-        const long long rem = ((long long)a.M - pix0) * a.cout2 * 2;
-        const int rem32 = (int)(rem > 0x7fffffffLL ? 0x7fffffffLL : rem);
-        __amdgpu_buffer_rsrc_t rs_wf = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2, 0, a.cout2 * 512, 0x00020000);
-        __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? a.res2 + (size_t)pix0 * a.cout2 : a.y2), 0, has_res ? rem32 : 0, 0x00020000);
-        __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)(a.y2 + (size_t)pix0 * a.cout2), 0, rem32, 0x00020000);
-        const int v_io = ((pg * 128 + e_px) * a.cout2 + e_ch * 8) * 2;   // lane part of a residual / output offset (pixel row, chunk)
-        const int row_b = a.cout2 * 2;                                    // bytes per pixel row
-        // All eight waves do the same work, pass after pass: left alone they run their MFMA phases together and then their output phases
-        // (VALU, LDS, vector memory) together, and the tail takes the SUM of the four (measured: 75 us per tile against ~20 us of MFMA time).
-        // A one-off start delay per wave -- the second wave of every SIMD by about one MFMA phase, the SIMDs a little against each other --
-        // makes the phases of different waves overlap.  Unit: s_sleep(8) = 512 cycles; a.stamp units per step (md_conv2d_set_expand_stagger).
-        for (int i = a.stamp * ((wave >> 2) * 4 + (wave & 3)); i > 0; --i) __builtin_amdgcn_s_sleep(8);
-        float bias_v = a.b2[cg * 64 + lane];
-        asm volatile("" : "+v"(bias_v));   // retired before the loop, so that the loop header's merged wait state carries no pending load
-        for (int q = 0; q < n_pass; ++q) {
-            const int c0 = q * 256 + cg * 64;          // this wave's first output channel in the pass
-            // the pass's biases were requested one pass ago: parking them in the slab must not wait for the previous pass's stores
-            b2w[lane] = bias_v;
-            bias_v = a.b2[(q + 1 < n_pass ? c0 + 256 : c0) + lane];
-            const int wf_s = (c0 >> 5) * 16384;        // byte offset of the wave's first 32-cout fragment block in w2f
-            // residual pieces of block n (cout block i = n & 1, pixel block j = n >> 1: the two 64-B halves of a pixel's 128-B line are
-            // read / written back to back): two 16-B loads per lane
-            u32x4 rr[4][2];
-            auto res_load = [&](int n, int it) -> u32x4 {
-                return __builtin_amdgcn_raw_buffer_load_b128(rs_r, v_io + ((n >> 1) * 32 + 16 * it) * row_b, (c0 + (n & 1) * 32) * 2, 2);
-            };
-            if (has_res) {
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-#pragma unroll
-                    for (int it = 0; it < 2; ++it) rr[n][it] = res_load(n, it);
-            }
-            f32x16 ac[2][4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) ac[i][j][e] = 0.f;
-            // W2 arrives FRAGMENT-MAJOR ([cout / 32][k-step][lane][8], packed by the host): one A-fragment load of the wave = 1 KiB
-            // contiguous (row-major rows would be 32 separate 32-B segments per load instruction)
-            u32x4 wa[4][2];   // ring of four k-steps
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                wa[s][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_wf, lane * 16, wf_s + s * 1024, 0);
-                wa[s][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_wf, lane * 16, wf_s + 16384 + s * 1024, 0);
-            }
-            const char *Eb = E + (pg * 128 + lr) * EP_STRIDE + lh * 16;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                if (s + 3 < 16) {
-                    wa[(s + 3) & 3][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_wf, lane * 16, wf_s + (s + 3) * 1024, 0);
-                    wa[(s + 3) & 3][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_wf, lane * 16, wf_s + 16384 + (s + 3) * 1024, 0);
-                }
-                // (without this fence hipcc sinks every A load to just in front of its first MFMA -- s_waitcnt vmcnt(0) per k-step, the
-                // L2 latency exposed 16 times per pass: the tail then ran 10x slower than its MFMAs)
-                __builtin_amdgcn_sched_barrier(0);
-                bf16x8 fb[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8 *>(Eb + j * 32 * EP_STRIDE + s * 32);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[s & 3][i]), fb[j], ac[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // the next pass's bias has long arrived (it is older than this pass's residual loads): retiring it HERE costs a counted wait;
-            // left to the loop's back edge hipcc waits with vmcnt(0), i.e. for this pass's stores
-            asm volatile("" : "+v"(bias_v));
-#pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                const int i = n & 1, j = n >> 1;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(b2w + i * 32 + 8 * g + 4 * lh);
-                    const f32x2 s01 = (f32x2){ac[i][j][4 * g + 0], ac[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
-                    const f32x2 s23 = (f32x2){ac[i][j][4 * g + 2], ac[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
-                    u32x2 pk;
-                    pk.x = pk_bf16(s01.x, s01.y);
-                    pk.y = pk_bf16(s23.x, s23.y);
-                    if (!has_res) { pk.x = pk_relu_bf16(pk.x); pk.y = pk_relu_bf16(pk.y); }
-                    *reinterpret_cast<u32x2 *>(slab + lr * 80 + 16 * g + 8 * lh) = pk;
-                }
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    u32x4 v = *reinterpret_cast<const u32x4 *>(slab + (e_px + 16 * it) * 80 + e_ch * 16);
-                    if (has_res) {
-                        const u32x4 rv = rr[n & 3][it];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const f32x2 sum = (f32x2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)} +
-                                              (f32x2){__uint_as_float(rv[k] << 16), __uint_as_float(rv[k] & 0xffff0000u)};
-                            v[k] = pk_relu_bf16(pk_bf16(sum.x, sum.y));
-                        }
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, v_io + (j * 32 + 16 * it) * row_b, (c0 + i * 32) * 2, 2);
-                }
-                if (has_res && n + 4 < 8) {   // the slot just consumed takes the residual of the block four ahead
-#pragma unroll
-                    for (int it = 0; it < 2; ++it) rr[n & 3][it] = res_load(n + 4, it);
-                }
-            }
-        }
-        return;
-    }
     if constexpr (HEAD) {
         // ---- fused head: y2[p][c2] = b2[c2] + sum_k W2[c2][k] * relu(conv)[p][k], K = 256 straight from the epilogue image.
         // v_mfma_f32_16x16x32_bf16 with A = W2 (16 head channels), B = 16 pixels; each wave owns 32 pixels.
@@ -1587,17 +1456,15 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 // +1.6 %, 50x84: +0.9 %) and a lower one on the short-K / small-grid layers (1x1 1024->256: -7 %, 3x3 512->512 at 25x42: -3 %).
 static bool pingpong_wants_16x16(const ConvArgs &a) { return a.kh == 3 && a.kw == 3 && a.Kpad >= 2304 && a.M >= 400000; }
 
-template <int MF, int TAIL>
-static int launch_conv_pingpong_tail_mf(ConvArgs &a, hipStream_t s, long long blocks, int lds) {
-    auto k = conv_pingpong_kernel<0, MF, 0, TAIL>;
+template <int MF>
+static int launch_conv_pingpong_head_mf(ConvArgs &a, hipStream_t s, long long blocks, int lds) {
+    auto k = conv_pingpong_kernel<0, MF, 0, true>;
     if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
-// the ping-pong kernel with a fused tail: the 1x1 head (TAIL 1) or the 1x1 expand conv (TAIL 2); the 256-channel conv output is never written
-template <int TAIL>
-static int launch_conv_pingpong_tail(ConvArgs &a, hipStream_t s) {
+static int launch_conv_pingpong_head(ConvArgs &a, hipStream_t s) {
     ++g_launch_count;
     g_last_kernel = MD_CONV_KERNEL_PINGPONG;
     a.n_ctiles = 1;
@@ -1605,10 +1472,8 @@ static int launch_conv_pingpong_tail(ConvArgs &a, hipStream_t s) {
     a.pt_per_xcd = (a.n_ptiles + 7) / 8;
     const long long blocks = (long long)a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
-    if (TAIL == 2) a.stamp = g_expand_stagger;
-    // epilogue image + bias + (head weights | eight wave-private 2.5-KiB transpose slabs with 64 biases each)
-    const int lds = 256 * (256 * 2 + 16) + 256 * 4 + (TAIL == 1 ? 16 * 256 * 2 : 8 * 3456);
-    return pingpong_wants_16x16(a) ? launch_conv_pingpong_tail_mf<1, TAIL>(a, s, blocks, lds) : launch_conv_pingpong_tail_mf<0, TAIL>(a, s, blocks, lds);
+    const int lds = 256 * (256 * 2 + 16) + 256 * 4 + 16 * 256 * 2;  // epilogue image + bias + head weights
+    return pingpong_wants_16x16(a) ? launch_conv_pingpong_head_mf<1>(a, s, blocks, lds) : launch_conv_pingpong_head_mf<0>(a, s, blocks, lds);
 }
 
 template <int ABL = 0, int MF = 0>
@@ -1655,12 +1520,6 @@ extern "C" int md_conv2d_set_stream_rounds(int rounds) {   // tools only: workgr
     return old;
 }
 
-extern "C" int md_conv2d_set_expand_stagger(int units) {   // tools only
-    const int old = g_expand_stagger;
-    g_expand_stagger = units >= 0 && units <= 64 ? units : 2;
-    return old;
-}
-
 extern "C" int md_conv2d_set_stream_tune(int wgs_per_cu, int cache_bits) {   // tools only
     g_stream_wgs_per_cu = wgs_per_cu >= 1 && wgs_per_cu <= 8 ? wgs_per_cu : 2;
     g_stream_tune = cache_bits & 7;
@@ -1669,12 +1528,10 @@ extern "C" int md_conv2d_set_stream_tune(int wgs_per_cu, int cache_bits) {   // 
 
 extern "C" int md_conv2d_cout_tile(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 
-struct HeadArgs {   // a fused tail of the ping-pong kernel (y is not written): the RPN head (y2 has 16 channels) or, cout2 > 0, the 1x1 expand conv
+struct HeadArgs {   // the fused RPN head: y2 has 16 channels, y is not written
     const uint16_t *w2;
     const float *b2;
     uint16_t *y2;
-    const uint16_t *res2 = nullptr;   // expand: residual [N,Ho,Wo,cout2] | null
-    int cout2 = 0;                    // expand: output channels (a multiple of 256); 0 = the 16-channel head
 };
 #ifdef MD_DIAG
 static unsigned long long *g_stamp_buf = nullptr;
@@ -1714,12 +1571,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
                 void *p2[5] = {(char *)params[0] + n0 * x_img, params[1], params[2],
                                params[3] ? (void *)((char *)params[3] + n0 * r_img) : nullptr, (char *)params[4] + n0 * y_img};
                 HeadArgs h2;
-                if (head) {
-                    h2 = *head;
-                    const long long c2 = head->cout2 ? head->cout2 : 16;
-                    h2.y2 += n0 * shapes[4][1] * shapes[4][2] * c2;
-                    if (h2.res2) h2.res2 += n0 * shapes[4][1] * shapes[4][2] * c2;
-                }
+                if (head) { h2 = *head; h2.y2 += n0 * shapes[4][1] * shapes[4][2] * 16; }
                 const int rc = conv2d_entry(nparam, p2, ndims, sh2, dtypes, stream, extra, head ? &h2 : nullptr);
                 if (rc != MD_OK) return rc;
             }
@@ -1849,8 +1701,8 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     const bool pp_ok = fast && dma_ok && a.Cout % 256 == 0 && a.Kpad >= 1024 && pp_blocks >= 128 && t_pp <= t_sb;
     if (head) {
         if (!(fast && dma_ok && a.Cout == 256 && !a.adv && !a.res && a.relu == 1 && pp_blocks >= 64)) return MD_ERR_UNSUPPORTED_INTERNAL;
-        a.w2 = head->w2; a.b2 = head->b2; a.y2 = head->y2; a.res2 = head->res2; a.cout2 = head->cout2;
-        return head->cout2 ? launch_conv_pingpong_tail<2>(a, s) : launch_conv_pingpong_tail<1>(a, s);
+        a.w2 = head->w2; a.b2 = head->b2; a.y2 = head->y2;
+        return launch_conv_pingpong_head(a, s);
     }
     // 3x3 layers on <= 256 channels: the 64-cout halo-reuse kernel at four workgroups per CU beats the 128x128 kernel wherever
     // the ping-pong kernel does not apply, and beats the ping-pong kernel when its 256x256 tiles fill the last of several rounds
@@ -1942,68 +1794,6 @@ extern "C" int md_conv2d_head(MD_AOT_ARGS) {
     int64_t *sh1[5] = {sy, sw2, sb2, snull, shapes[5]};
     const char *dt1[5] = {"bfloat16", "bfloat16", "float32", nullptr, "bfloat16"};
     void *p1[5] = {tmp.ptr, params[3], params[4], nullptr, params[5]};
-    return conv2d_entry(5, p1, nd1, sh1, dt1, stream, &a1, nullptr);
-}
-
-// conv (Cout = 256, ReLU; the ping-pong kernel's layers) followed by a 1x1 EXPAND conv + residual + ReLU in one launch: the second half
-// of a ResNet bottleneck block with 256 mid channels (centernet/src/resnet.py:139-178: relu(bn2(conv2)) -> bn3(conv3) + identity -> relu).
-// The 256-channel intermediate never leaves the CU; where the fused kernel does not apply the two convolutions run back to back
-// through a stream-ordered temporary (or the caller's workspace) -- same arithmetic and rounding points either way (bit-identical).
-// in : x[N,H,W,Cin] bf16, w[256,Kpad] bf16, bias[256] f32, w3[Cout3_pad,256] bf16, b3[Cout3_pad] f32,
-//      w3f[Cout3/32,16,64,8] bf16 | NULL (w3 fragment-major: element (cb, s, lane, e) = w3[32 cb + lane % 32][16 s + 8 (lane / 32) + e]; NULL: two launches),
-//      residual[N,Ho,Wo,Cout3] bf16 | NULL ; out: y[N,Ho,Wo,Cout3] bf16 ; [workspace].
-// extra: md_conv2d_attrs of the FIRST conv (relu must be 1, no adv / upsampled residual)
-extern "C" int md_conv2d_expand(MD_AOT_ARGS) {
-    if (nparam != 8 && nparam != 9) return MD_ERR_NPARAM;
-    if (!params || !extra || !ndims || !shapes || !params[1] || !params[2] || !params[3] || !params[4]) return MD_ERR_ARG;
-    if (!dtype_is(dtypes, 0, "bfloat16") || !dtype_is(dtypes, 3, "bfloat16") || !dtype_is(dtypes, 4, "float32") || !dtype_is(dtypes, 7, "bfloat16") ||
-        (params[5] && !dtype_is(dtypes, 5, "bfloat16")) || (params[6] && !dtype_is(dtypes, 6, "bfloat16")))
-        return MD_ERR_ARG;
-    if (ndims[0] != 4 || ndims[1] != 2 || ndims[3] != 2 || ndims[7] != 4) return MD_ERR_ARG;
-    const md_conv2d_attrs *at = (const md_conv2d_attrs *)extra;
-    if (at->adv || at->relu != 1 || at->res_upsample || at->x_cin > 0 || at->res_slice) return MD_ERR_ARG;
-    const int64_t N = shapes[7][0], Ho = shapes[7][1], Wo = shapes[7][2], C3 = shapes[7][3];
-    const int64_t c3_pad = (C3 + 127) / 128 * 128;
-    if (shapes[1][0] != 256 || shapes[3][0] != c3_pad || shapes[3][1] != 256 || numel(ndims, shapes, 4) != c3_pad || C3 % 8 || C3 <= 64 ||
-        shapes[0][0] != N)
-        return MD_ERR_ARG;
-    if (params[5] && (C3 % 32 || numel(ndims, shapes, 5) != C3 * 256)) return MD_ERR_ARG;
-    if (params[6] && (ndims[6] != 4 || numel(ndims, shapes, 6) != N * Ho * Wo * C3)) return MD_ERR_ARG;
-    if (N * Ho * Wo == 0) return MD_OK;
-    if (!params[0] || !params[7]) return MD_ERR_ARG;
-    // the first conv as md_conv2d sees it: residual NULL, output [N,Ho,Wo,256]
-    int64_t sy[4] = {N, Ho, Wo, 256}, snull[1] = {0};
-    int nd5[5] = {ndims[0], ndims[1], ndims[2], 0, 4};
-    int64_t *sh5[5] = {shapes[0], shapes[1], shapes[2], snull, sy};
-    const char *dt5[5] = {dtypes ? dtypes[0] : nullptr, dtypes ? dtypes[1] : nullptr, dtypes ? dtypes[2] : nullptr, nullptr, "bfloat16"};
-    void *p5[5] = {params[0], params[1], params[2], nullptr, params[7] /* placeholder, not written by the fused kernel */};
-    int rc = MD_ERR_UNSUPPORTED_INTERNAL;
-    if (C3 % 256 == 0 && params[5] && params[6] && at->variant != 31) {
-        HeadArgs tail;
-        tail.w2 = (const uint16_t *)params[5]; tail.b2 = (const float *)params[4]; tail.y2 = (uint16_t *)params[7];
-        tail.res2 = (const uint16_t *)params[6]; tail.cout2 = (int)C3;
-        md_conv2d_attrs a0 = *at;
-        a0.variant = 0;
-        rc = conv2d_entry(5, p5, nd5, sh5, dt5, stream, &a0, &tail);
-    }
-    if (rc != MD_ERR_UNSUPPORTED_INTERNAL) return rc;
-    // two launches through a temporary [N,Ho,Wo,256]
-    Scratch tmp;
-    const size_t bytes = (size_t)(N * Ho * Wo) * 256 * 2;
-    rc = tmp.acquire(bytes, nparam, params, ndims, shapes, 8, (hipStream_t)stream);
-    if (rc != MD_OK) return rc;
-    p5[4] = tmp.ptr;
-    md_conv2d_attrs a0 = *at;
-    if (a0.variant == 31) a0.variant = 0;
-    rc = conv2d_entry(5, p5, nd5, sh5, dt5, stream, &a0, nullptr);
-    if (rc != MD_OK) return rc;
-    md_conv2d_attrs a1 = {};
-    a1.kh = a1.kw = 1; a1.stride = 1; a1.pad = 0; a1.relu = 1; a1.variant = 0;
-    int64_t sw3[2] = {c3_pad, 256}, sb3[1] = {c3_pad};
-    int nd1[5] = {4, 2, 1, params[6] ? 4 : 0, 4};
-    int64_t *sh1[5] = {sy, sw3, sb3, params[6] ? shapes[6] : snull, shapes[7]};
-    const char *dt1[5] = {"bfloat16", "bfloat16", "float32", params[6] ? "bfloat16" : nullptr, "bfloat16"};
-    void *p1[5] = {tmp.ptr, params[3], params[4], params[6], params[7]};
     return conv2d_entry(5, p1, nd1, sh1, dt1, stream, &a1, nullptr);
 }
 

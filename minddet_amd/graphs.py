@@ -26,9 +26,6 @@ FUSE_BLOCKS = os.environ.get("MD_FUSE_BLOCKS", "1") == "1"
 # first block of the later stages: conv3 + the strided 1x1 downsample conv as one K-concatenated GEMM (md_conv1x1_dual; MD_FUSE_DUAL=0: two launches)
 FUSE_DUAL = os.environ.get("MD_FUSE_DUAL", "1") == "1"
 RPN_FUSED_HEAD = os.environ.get("MD_RPN_FUSED", "1") == "1"  # 0: two md_conv2d launches per level (A/B)
-# identity bottleneck blocks with 256 mid channels (ResNet-50 / 101 stage 3): conv2 3x3 and conv3 1x1 + residual + ReLU as ONE launch
-# (md_conv2d_expand: the 256-channel intermediate stays in LDS; bit-identical; MD_FUSE_EXPAND=0: two launches)
-FUSE_EXPAND = os.environ.get("MD_FUSE_EXPAND", "1") == "1"
 
 
 class ParamInit:
@@ -141,9 +138,6 @@ class Bottleneck:
             if self._dual is not None:
                 return nn_ops.conv1x1_dual(self.conv2(self.conv1(x)), x, self._dual)
         residual = self.downsample(x) if self.downsample is not None else x
-        if FUSE_EXPAND and nn_ops.expand_ok(self.conv2.packed, self.conv3.packed):
-            # 256 mid channels (R50 / R101 stage 3): conv2 3x3 -> conv3 1x1 + residual + ReLU as ONE launch (md_conv2d_expand)
-            return nn_ops.conv2d_expand(self.conv1(x), self.conv2.packed, self.conv3.packed, residual=residual)
         return self.conv3(self.conv2(self.conv1(x)), residual=residual)
 
 

@@ -139,40 +139,6 @@ def conv2d_head(x, pc, pc2, variant=None):
     return y2
 
 
-def expand_ok(pc, pc3):
-    """conv `pc` (any kernel size, 256 output channels, ReLU) followed by the 1x1 conv `pc3` + residual + ReLU: the pair
-    md_conv2d_expand takes (the second half of a ResNet bottleneck block with 256 mid channels)."""
-    return (pc.cout == 256 and pc.relu == 1 and pc3.kh == 1 and pc3.kw == 1 and pc3.stride == 1 and pc3.pad == 0 and pc3.cin == 256 and
-            pc3.relu == 1 and pc3.cout > 64 and tuple(pc3.w.shape)[1] == 256 and tuple(pc.w.shape)[0] == 256)
-
-
-def pack_expand(pc3):
-    """pc3.w [Cout3_pad, 256] -> the MFMA-fragment order md_conv2d_expand's fused kernel loads its A operands from:
-    [Cout3/32, 16 k-steps, 64 lanes, 8], element (cb, s, lane, e) = w[32 cb + lane % 32][16 s + 8 (lane // 32) + e]; None when
-    Cout3 is not a multiple of 32 (the op then always runs as two launches)."""
-    if pc3.cout % 32:
-        return None
-    w = pc3.w[:pc3.cout].reshape(pc3.cout // 32, 32, 16, 2, 8)          # [cb, lr, s, lh, e]
-    return w.permute(0, 2, 3, 1, 4).reshape(pc3.cout // 32, 16, 64, 8).contiguous()
-
-
-def conv2d_expand(x, pc, pc3, residual=None, variant=None):
-    """y = relu(conv3(relu(conv(x))) + residual) in one md_conv2d_expand call: [N,H,W,Cin] -> [N,Ho,Wo,pc3.cout] bf16.  One launch where
-    the fused ping-pong kernel applies (pc3.cout % 256 == 0), two launches through a stream-ordered temporary otherwise;
-    bit-identical either way.  variant 31 forces the two-launch path (A/B)."""
-    n, h, w, c = x.shape
-    if c != pc.cin or not expand_ok(pc, pc3):
-        raise _lib.MindDetHipError("conv2d_expand: needs a 256-channel ReLU conv followed by a 1x1 ReLU conv on 256 channels")
-    if not hasattr(pc3, "w_frag"):
-        pc3.w_frag = pack_expand(pc3)      # packed once per layer
-    ho, wo = conv_out_hw(h, w, pc)
-    y = torch.empty((n, ho, wo, pc3.cout), dtype=torch.bfloat16, device=x.device)
-    attrs = _ConvAttrs(pc.kh, pc.kw, pc.stride, pc.pad, 1, int(CONV_VARIANT if variant is None else variant))
-    attrs.korder = getattr(pc, "korder", 0)
-    _lib.call("md_conv2d_expand", [x, pc.w, pc.bias, pc3.w, pc3.bias, pc3.w_frag, residual, y], extra=attrs)
-    return y
-
-
 class PackedBottleneck:
     """The three packed convs of a stride-1 bottleneck block with 64 mid channels (+ its 1x1 downsample conv), as md_bottleneck
     consumes them."""

@@ -605,92 +605,3 @@ def test_conv1x1_stream_kernel_many_tiles_per_workgroup_and_rounds():
         x = torch.randn((1, 20, 24, Cin), generator=g).to(torch.bfloat16).to(DEV)
         assert torch.equal(nn_ops.conv2d(x, pc, variant=30), nn_ops.conv2d(x, pc, variant=0))
         assert lib.md_conv2d_last_kernel() != 8
-
-
-@pytest.mark.parametrize("cfg", [
-    # name, N, H, W, Cin, k, stride, Cout3, residual
-    ("r50_stage3_block", 4, 50, 84, 256, 3, 1, 1024, True),
-    ("many_tiles_16x16_mfma", 8, 50, 84, 256, 3, 1, 1024, True),       # M >= 400 000 is not reached here; the MF 1 form is covered below
-    ("ragged", 12, 37, 41, 256, 3, 1, 512, True),
-    ("fallback_no_residual", 12, 37, 41, 256, 3, 1, 512, False),
-    ("strided_3x3", 16, 64, 72, 256, 3, 2, 1024, True),
-    ("k1_1024_to_256_then_expand", 14, 30, 44, 1024, 1, 1, 256, True),
-    ("fallback_cout3_384", 1, 40, 40, 256, 3, 1, 384, True),
-    ("fallback_tiny_grid", 1, 8, 8, 256, 3, 1, 1024, True),
-], ids=lambda c: c[0])
-def test_conv2d_expand_fused_equals_two_launches(cfg):
-    """md_conv2d_expand (3x3 conv + ReLU -> 1x1 expand conv + residual + ReLU inside the ping-pong kernel) against the two md_conv2d
-    launches it replaces: bit-identical (same MFMA k-order, bf16 rounding after each conv and after the residual add), on the fused
-    path and on the library's own two-launch fallback (variant 31 / layers the fused kernel does not take)."""
-    from minddet_amd import _lib, nn_ops
-
-    name, N, H, W, Cin, k, stride, C3, use_res = cfg
-    g = torch.Generator().manual_seed(len(name) + C3)
-    w2 = torch.randn((256, Cin, k, k), generator=g) * (2.0 / (k * k * Cin)) ** 0.5
-    w3 = torch.randn((C3, 256, 1, 1), generator=g) * (2.0 / 256) ** 0.5
-    pc2 = nn_ops.pack_conv(w2, bias=torch.randn((256,), generator=g) * 0.1, stride=stride, pad=k // 2, relu=True).to(DEV)
-    pc3 = nn_ops.pack_conv(w3, bias=torch.randn((C3,), generator=g) * 0.1, relu=True).to(DEV)
-    x = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16).to(DEV)
-    ho, wo = nn_ops.conv_out_hw(H, W, pc2)
-    r = torch.randn((N, ho, wo, C3), generator=g).to(torch.bfloat16).to(DEV) if use_res else None
-    ref = nn_ops.conv2d(nn_ops.conv2d(x, pc2, variant=31), pc3, residual=r, variant=31)
-    lib = _lib.lib()
-    lib.md_conv2d_launch_count.restype = ctypes.c_longlong
-    n0 = lib.md_conv2d_launch_count()
-    got = nn_ops.conv2d_expand(x, pc2, pc3, residual=r)
-    torch.cuda.synchronize()
-    assert lib.md_conv2d_launch_count() - n0 == (2 if name.startswith("fallback") else 1)   # fused: ONE kernel launch
-    assert torch.equal(got, ref)
-    n0 = lib.md_conv2d_launch_count()
-    assert torch.equal(nn_ops.conv2d_expand(x, pc2, pc3, residual=r, variant=31), ref)
-    assert lib.md_conv2d_launch_count() - n0 == 2
-    # fp32 sanity on a crop of the first image
-    t2 = torch.relu(F.conv2d(x[:1].float().cpu().permute(0, 3, 1, 2), w2.to(torch.bfloat16).float(), pc2.bias[:256].float().cpu(), stride=stride, padding=k // 2))
-    y = F.conv2d(t2.to(torch.bfloat16).float(), w3.to(torch.bfloat16).float(), pc3.bias[:C3].float().cpu()).permute(0, 2, 3, 1)
-    if use_res:
-        y = y.to(torch.bfloat16).float() + r[:1].float().cpu()
-    y = torch.relu(y)
-    assert ((ref[:1].float().cpu() - y).abs() <= 3e-2 * y.abs() + 3e-2).all()
-
-
-def test_conv2d_expand_16x16_mfma_form_and_chunked_batch():
-    """M >= 400 000 pixels: the ping-pong main loop runs on v_mfma_f32_16x16x32_bf16 (its own epilogue-image writer) in front of
-    the fused expand conv; and a batch past the (lowered) chunk limit runs as image chunks with y / residual advanced per chunk."""
-    from minddet_amd import _lib, nn_ops
-
-    g = torch.Generator().manual_seed(11)
-    w2 = torch.randn((256, 256, 3, 3), generator=g) * (2.0 / 2304) ** 0.5
-    w3 = torch.randn((512, 256, 1, 1), generator=g) * (2.0 / 256) ** 0.5
-    pc2 = nn_ops.pack_conv(w2, bias=torch.randn((256,), generator=g) * 0.1, stride=1, pad=1, relu=True).to(DEV)
-    pc3 = nn_ops.pack_conv(w3, bias=torch.randn((512,), generator=g) * 0.1, relu=True).to(DEV)
-    x = torch.randn((12, 200, 168, 256), generator=g).to(torch.bfloat16).to(DEV)   # 403 200 pixels
-    r = torch.randn((12, 200, 168, 512), generator=g).to(torch.bfloat16).to(DEV)
-    ref = nn_ops.conv2d(nn_ops.conv2d(x, pc2, variant=31), pc3, residual=r, variant=31)
-    assert torch.equal(nn_ops.conv2d_expand(x, pc2, pc3, residual=r), ref)
-    lib = _lib.lib()
-    lib.md_conv2d_set_chunk_limit.restype = ctypes.c_longlong
-    old = lib.md_conv2d_set_chunk_limit(ctypes.c_longlong(5 * 200 * 168 * 256 * 2 + 1))
-    try:
-        n0 = lib.md_conv2d_launch_count()
-        got = nn_ops.conv2d_expand(x, pc2, pc3, residual=r)
-        assert lib.md_conv2d_launch_count() - n0 == 3   # 12 images as 3 chunks of 4
-    finally:
-        lib.md_conv2d_set_chunk_limit(ctypes.c_longlong(old))
-    assert torch.equal(got, ref)
-
-
-def test_conv2d_expand_argument_checks():
-    from minddet_amd import _lib, nn_ops
-
-    pc2 = nn_ops.pack_conv(torch.randn((256, 256, 3, 3)) * 0.02, stride=1, pad=1, relu=True).to(DEV)
-    pc3 = nn_ops.pack_conv(torch.randn((512, 256, 1, 1)) * 0.05, relu=True).to(DEV)
-    x = torch.zeros((1, 16, 16, 256), dtype=torch.bfloat16, device=DEV)
-    with pytest.raises(_lib.MindDetHipError):   # residual of the wrong shape
-        nn_ops.conv2d_expand(x, pc2, pc3, residual=torch.zeros((1, 16, 16, 256), dtype=torch.bfloat16, device=DEV))
-    with pytest.raises(_lib.MindDetHipError):   # first conv without ReLU
-        nn_ops.conv2d_expand(x, nn_ops.pack_conv(torch.randn((256, 256, 3, 3)) * 0.02, stride=1, pad=1, relu=False).to(DEV), pc3)
-    with pytest.raises(_lib.MindDetHipError):   # 128 mid channels
-        nn_ops.conv2d_expand(torch.zeros((1, 16, 16, 128), dtype=torch.bfloat16, device=DEV),
-                             nn_ops.pack_conv(torch.randn((128, 128, 3, 3)) * 0.02, stride=1, pad=1, relu=True).to(DEV), pc3)
-    e = nn_ops.conv2d_expand(torch.zeros((0, 16, 16, 256), dtype=torch.bfloat16, device=DEV), pc2, pc3)   # empty batch
-    assert e.shape == (0, 16, 16, 512)
