@@ -13,10 +13,10 @@ run_cfg() {  # name config batch
 }
 python bench.py --steps 20 --warmup 5 > $OUT/frcnn_bench.json 2> $OUT/frcnn_bench.err
 tail -c 1500 $OUT/frcnn_bench.json; echo
-run_cfg frcnn_all configs/faster_rcnn/faster_rcnn_r50_fpn.py 60
+run_cfg frcnn_all configs/faster_rcnn/faster_rcnn_r50_fpn.py 120
 run_cfg yolov5s configs/yolov5/yolov5s.py 32
 run_cfg yolov8l configs/yolov8/yolov8l.py 32
-for c in "frcnn configs/faster_rcnn/faster_rcnn_r50_fpn.py 60" "yolov5s configs/yolov5/yolov5s.py 32" "yolov8l configs/yolov8/yolov8l.py 32"; do
+for c in "frcnn configs/faster_rcnn/faster_rcnn_r50_fpn.py 120" "yolov5s configs/yolov5/yolov5s.py 32" "yolov8l configs/yolov8/yolov8l.py 32"; do
   set -- $c
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_$1 -- python3 $ROOT/bench.py --config $ROOT/$2 --batch $3 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-zero-operands --no-from-uint8 > $ROOT/$OUT/prof_$1.log 2>&1)
   f=$(ls $OUT/prof_$1/*/*kernel_stats.csv | head -1)
