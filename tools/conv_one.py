@@ -1,5 +1,5 @@
 """Run ONE conv layer shape repeatedly (for rocprofv3 --pmc passes). Usage:
-python tools/conv_one.py H W Cin Cout k stride batch variant reps"""
+python tools/conv_one.py H W Cin Cout k stride batch variant reps [residual 0|1]"""
 import os
 import sys
 
@@ -9,11 +9,14 @@ import torch
 from minddet_amd import nn_ops
 
 H, W, Cin, Cout, k, s, B, variant, reps = [int(v) for v in sys.argv[1:10]]
+use_res = len(sys.argv) > 10 and int(sys.argv[10]) != 0
 g = torch.Generator().manual_seed(0)
 w = torch.randn((Cout, Cin, k, k), generator=g) * (2.0 / (k * k * Cin)) ** 0.5
 pc = nn_ops.pack_conv(w, stride=s, pad=k // 2, relu=True).to("cuda:0")
 x = torch.randn((B, H, W, pc.cin), generator=g).to(torch.bfloat16).to("cuda:0")
+ho, wo = nn_ops.conv_out_hw(H, W, pc)
+r = torch.randn((B, ho, wo, pc.cout), generator=g).to(torch.bfloat16).to("cuda:0") if use_res else None
 for _ in range(reps):
-    y = nn_ops.conv2d(x, pc, variant=variant)
+    y = nn_ops.conv2d(x, pc, residual=r, variant=variant)
 torch.cuda.synchronize()
 print("done", tuple(y.shape))
