@@ -266,10 +266,10 @@ def main(argv=None):
     H, W = cfg.data.input_hw
     B = args.batch
     images = synthetic_images(B, H, W, seed=20240317 + rank, device=dev)
-    if (type(model).__name__ in ("FasterRCNN", "MaskRCNN") and nn_ops.stem_layout_ok(H, W) and os.environ.get("MD_STEM_LAYOUT", "1") == "1"
-            and getattr(model.backbone, "stem", None) is not None):
+    has_stem = getattr(getattr(model, "backbone", None), "stem", None) is not None or getattr(model, "stem", None) is not None
+    if nn_ops.stem_layout_ok(H, W) and os.environ.get("MD_STEM_LAYOUT", "1") == "1" and has_stem:
         # the batch is resident in HBM in the model's input layout before the timed region starts: zero-bordered
-        # 4-channel NHWC (md_stem_pool); MD_STEM_LAYOUT=0 keeps the 8-channel layout + two-launch stem for A/B
+        # 4-channel NHWC (md_stem_pool for the ResNet stems, md_stem_conv for the YOLO stems); MD_STEM_LAYOUT=0 keeps the 8-channel layout for A/B
         images = nn_ops.to_stem_layout(images)
 
     # ---- per-conv event instrumentation (roofline of the dominant kernel)

@@ -304,6 +304,20 @@ int md_deform_cols(MD_AOT_ARGS);
  *      w[64, 224] bf16 -- BN-folded weights, K = (ky 0..6, kx 0..7, c 0..3) with kx 7 and c 3 zero; bias[64] f32
  * out: y[N, H/4, W/4, 64] bf16.   H % 16 == 0 and W % 64 == 0 (else MD_ERR_ARG: use md_conv2d + md_maxpool2d). */
 int md_stem_pool(MD_AOT_ARGS);
+
+/* The first convolution of the one-stage detectors on the same STEM LAYOUT input: 3 input channels, stride 2, folded BN, activation --
+ * YOLOv5 v6 stem 6x6 / s2 / p2 and YOLOv8 stem 3x3 / s2 / p1 (configs/yolov5, configs/yolov8; conv + BN + activation cells like
+ * minddet/models/centernet/src/resnet.py:199-204).  Weights in registers, the raw input patch in LDS (no im2col, padding taps read
+ * real zeros), 4-channel input: see csrc/stemconv.hip.
+ * in : x[N, H+16, W+16, 4] bf16 (stem layout), w[COUT, K] bf16 with K = (ky, kx', c 0..3), c 3 zero --
+ *        kh = 6: K = 192, kx' = kx + 1 in 0..7 (columns 0 and 7 zero: the 6-tap window runs as an aligned 8-tap window);
+ *        kh = 3: K = 48,  kx' = kx in 0..3 (column 3 zero);
+ *      bias[COUT] f32 ; out: y[N, H/2, W/2, COUT] bf16, COUT = 32 or 64.  H % 16 == 0 and W % 64 == 0 (else MD_ERR_ARG: use md_conv2d). */
+typedef struct md_stem_conv_attrs {
+    int32_t kh;   /* 6 or 3 (square kernel, stride 2, pad kh / 2 - (kh == 6)) */
+    int32_t act;  /* 0 none, 1 ReLU, 2 SiLU */
+} md_stem_conv_attrs;
+int md_stem_conv(MD_AOT_ARGS);
 int md_stem_layout_pad(int which);
 
 /* FPN top-down step: in lateral[N,H,W,C], top[N,Ht,Wt,C] bf16 ; out y = lateral + nearest_up(top). */

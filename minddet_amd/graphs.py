@@ -843,10 +843,21 @@ class YOLOv5:
     def to(self, device):
         for m in self.conv_modules():
             m.to(device)
+        # the 3-channel stride-2 stem conv on the 4-channel stem layout (md_stem_conv) when the batch arrives in it
+        self.stem = nn_ops.pack_stem_conv(self.b0.weight, bn=self.b0.bn, bias=self.b0.bias, act=self.b0.act)
+        if self.stem is not None:
+            self.stem.to(device)
         return self
 
     def features(self, x):
-        x = self.b3(self.b2(self.b1(self.b0(x))))
+        """x: [N,H,W,8] bf16 NHWC (3 real channels), or the batch in the stem layout ([N,H+16,W+16,4], nn_ops.to_stem_layout)."""
+        if x.shape[3] == 4:
+            if self.stem is None:
+                raise nn_ops._lib.MindDetHipError("stem-layout input needs a 6x6 / 3x3 stride-2 stem conv with 32 or 64 output channels")
+            x = nn_ops.stem_conv(x, self.stem)
+        else:
+            x = self.b0(x)
+        x = self.b3(self.b2(self.b1(x)))
         # p3 / p4 are produced straight into the second half of the PAN concat buffers that consume them later
         # ([upsampled top | skip]); the next backbone conv reads them as a channel slice
         n, h, w, _ = x.shape
@@ -994,10 +1005,21 @@ class YOLOv8:
     def to(self, device):
         for m in self.conv_modules():
             m.to(device)
+        # the 3-channel stride-2 stem conv on the 4-channel stem layout (md_stem_conv) when the batch arrives in it
+        self.stem = nn_ops.pack_stem_conv(self.b0.weight, bn=self.b0.bn, bias=self.b0.bias, act=self.b0.act)
+        if self.stem is not None:
+            self.stem.to(device)
         return self
 
     def features(self, x):
-        x = self.b3(self.b2(self.b1(self.b0(x))))
+        """x: [N,H,W,8] bf16 NHWC (3 real channels), or the batch in the stem layout ([N,H+16,W+16,4], nn_ops.to_stem_layout)."""
+        if x.shape[3] == 4:
+            if self.stem is None:
+                raise nn_ops._lib.MindDetHipError("stem-layout input needs a 6x6 / 3x3 stride-2 stem conv with 32 or 64 output channels")
+            x = nn_ops.stem_conv(x, self.stem)
+        else:
+            x = self.b0(x)
+        x = self.b3(self.b2(self.b1(x)))
         # p3 / p4 are produced straight into the PAN concat buffers that consume them later ([upsampled top | skip]); the next
         # backbone conv reads them as a channel slice
         n, h, w, _ = x.shape

@@ -374,6 +374,52 @@ def pack_stem(weight, bn=None, bias=None):
     return PackedStem(wp.reshape(64, 224).to(torch.bfloat16).contiguous(), b.contiguous())
 
 
+class _StemConvAttrs(ctypes.Structure):
+    _fields_ = [("kh", ctypes.c_int32), ("act", ctypes.c_int32)]
+
+
+class PackedStemConv:
+    def __init__(self, w, bias, kh, act, cout):
+        self.w, self.bias, self.kh, self.act, self.cout = w, bias, kh, act, cout
+
+    def to(self, device):
+        self.w, self.bias = self.w.to(device), self.bias.to(device)
+        return self
+
+
+def pack_stem_conv(weight, bn=None, bias=None, act=None):
+    """weight [Cout, <=3, k, k] fp32 (+ eval BatchNorm) of a stride-2 stem conv with k = 6 (pad 2) or k = 3 (pad 1), Cout 32 or 64
+    -> md_stem_conv operands, or None when the layer is not one it takes.  K = (ky, kx', c 0..3): k = 6 -> kx' = kx + 1 in 0..7,
+    k = 3 -> kx' = kx in 0..3."""
+    weight = weight.detach().to(torch.float32)
+    cout, cin, kh, kw = weight.shape
+    if kh != kw or kh not in (6, 3) or cin > 3 or cout not in (32, 64):
+        return None
+    if bn is not None:
+        gamma, beta, mean, var, eps = bn
+        scale = gamma.to(torch.float32) / torch.sqrt(var.to(torch.float32) + eps)
+        weight = weight * scale.view(-1, 1, 1, 1)
+        b = beta.to(torch.float32) - mean.to(torch.float32) * scale
+        if bias is not None:
+            b = b + bias.to(torch.float32) * scale
+    else:
+        b = bias.detach().to(torch.float32) if bias is not None else torch.zeros(cout)
+    kx, x0 = (8, 1) if kh == 6 else (4, 0)
+    wp = torch.zeros((cout, kh, kx, 4), dtype=torch.float32)
+    wp[:, :, x0:x0 + kw, :cin] = weight.permute(0, 2, 3, 1)
+    code = {None: 0, False: 0, True: 1, "relu": 1, "silu": 2, 0: 0, 1: 1, 2: 2}[act]
+    return PackedStemConv(wp.reshape(cout, kh * kx * 4).to(torch.bfloat16).contiguous(), b.contiguous(), kh, code, cout)
+
+
+def stem_conv(x4, ps):
+    """x4: the batch in the stem layout [N, H+16, W+16, 4] -> [N, H/2, W/2, Cout] bf16 (md_stem_conv)."""
+    n, hp, wp, c = x4.shape
+    h, w = hp - STEM_PAD_LO - STEM_PAD_HI, wp - STEM_PAD_LO - STEM_PAD_HI
+    y = torch.empty((n, h // 2, w // 2, ps.cout), dtype=torch.bfloat16, device=x4.device)
+    _lib.call("md_stem_conv", [x4, ps.w, ps.bias, y], extra=_StemConvAttrs(ps.kh, ps.act))
+    return y
+
+
 def stem_layout_ok(h, w):
     return h % 16 == 0 and w % 64 == 0
 
