@@ -605,3 +605,36 @@ def test_conv1x1_stream_kernel_many_tiles_per_workgroup_and_rounds():
         x = torch.randn((1, 20, 24, Cin), generator=g).to(torch.bfloat16).to(DEV)
         assert torch.equal(nn_ops.conv2d(x, pc, variant=30), nn_ops.conv2d(x, pc, variant=0))
         assert lib.md_conv2d_last_kernel() != 8
+
+
+def test_conv1x1_stream_kernel_random_shapes_against_the_tile_kernel():
+    """40 seeded random pointwise layers (ragged pixel counts from one tile to many tiles per workgroup, both K, all output widths,
+    residual kinds, workgroup rounds): conv1x1_stream_kernel == conv_igemm_kernel bit for bit."""
+    from minddet_amd import _lib, nn_ops
+
+    lib = _lib.lib()
+    rng = np.random.default_rng(20260101)
+    g = torch.Generator().manual_seed(77)
+    for case in range(40):
+        cin = int(rng.choice([128, 256, 512]))
+        cout = int(rng.choice([128, 256, 384, 512, 768, 1024]))
+        n, h, w = int(rng.integers(1, 5)), int(rng.integers(1, 90)), int(rng.integers(1, 90))
+        kind = int(rng.integers(0, 3))       # 0 none, 1 residual, 2 upsampled residual
+        act = ["none", "relu", "silu"][int(rng.integers(0, 3))] if kind != 2 else "none"
+        rounds = int(rng.choice([1, 2, 5]))
+        wt = torch.randn((cout, cin, 1, 1), generator=g) * (2.0 / cin) ** 0.5
+        pc = nn_ops.pack_conv(wt, bias=torch.randn((cout,), generator=g) * 0.1, relu={"none": 0, "relu": 1, "silu": "silu"}[act]).to(DEV)
+        x = torch.randn((n, h, w, cin), generator=g).to(torch.bfloat16).to(DEV)
+        r = None
+        if kind == 1:
+            r = torch.randn((n, h, w, cout), generator=g).to(torch.bfloat16).to(DEV)
+        elif kind == 2:
+            r = torch.randn((n, (h + 1) // 2, (w + 1) // 2, cout), generator=g).to(torch.bfloat16).to(DEV)
+        ref = nn_ops.conv2d(x, pc, residual=r, res_upsample=kind == 2, variant=20)
+        old = lib.md_conv2d_set_stream_rounds(rounds)
+        try:
+            got = nn_ops.conv2d(x, pc, residual=r, res_upsample=kind == 2, variant=30)
+        finally:
+            lib.md_conv2d_set_stream_rounds(old)
+        assert lib.md_conv2d_last_kernel() == 8, (case, cin, cout)
+        assert torch.equal(got, ref), (case, cin, cout, n, h, w, kind, act, rounds)
