@@ -35,6 +35,11 @@ typedef __attribute__((ext_vector_type(8))) short bn_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float bn_f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int bn_u32x4;
 typedef float bn_f32x2 __attribute__((ext_vector_type(2)));
+// LDS accesses below use BUILTIN vector types only: hipcc's waitcnt pass puts s_waitcnt vmcnt(0) in front of an LDS access without type-based
+// alias info (HIP's float4 / uint2 structs) while LDS-DMAs are pending -- r02: that drained the W2-tap / W3 DMAs in front of the T1 / T2
+// epilogues instead of letting the epilogue math run under their latency
+typedef float bn_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(2))) unsigned int bn_u32x2;
 
 struct BottleneckArgs {
     const uint16_t *x;    // [N,H,W,Cin]
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 bv = *reinterpret_cast<const float4 *>(bias12 + 128 + 64 * q + 32 * wc + 8 * g + 4 * lh);
+                    const bn_f32x4 bv = *reinterpret_cast<const bn_f32x4 *>(bias12 + 128 + 64 * q + 32 * wc + 8 * g + 4 * lh);
                     resd[q][2 * g + 0] = bn_pk_bf16(accd[4 * g + 0] + bv.x, accd[4 * g + 1] + bv.y);
                     resd[q][2 * g + 1] = bn_pk_bf16(accd[4 * g + 2] + bv.z, accd[4 * g + 3] + bv.w);
                 }
@@ -263,12 +268,12 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c_local = 32 * wc + 8 * g + 4 * lh;
-                const float4 bv = *reinterpret_cast<const float4 *>(bias12 + c_local);
-                uint2 pk;
+                const bn_f32x4 bv = *reinterpret_cast<const bn_f32x4 *>(bias12 + c_local);
+                bn_u32x2 pk;
                 pk.x = bn_pk_relu(bn_pk_bf16(acc1[j][4 * g + 0] + bv.x, acc1[j][4 * g + 1] + bv.y));
                 pk.y = bn_pk_relu(bn_pk_bf16(acc1[j][4 * g + 2] + bv.z, acc1[j][4 * g + 3] + bv.w));
                 if (!ok) pk.x = pk.y = 0u;
-                *reinterpret_cast<uint2 *>(T1 + r * BN_ROWB + (((4 * wc + g) ^ ((r >> 1) & 7)) << 4) + 8 * lh) = pk;
+                *reinterpret_cast<bn_u32x2 *>(T1 + r * BN_ROWB + (((4 * wc + g) ^ ((r >> 1) & 7)) << 4) + 8 * lh) = pk;
             }
         }
     }
@@ -310,9 +315,9 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
     BN_STAMP(5);
 #pragma unroll
     for (int t = 5; t < 9; ++t) tap_mfma(t, smem + BN_A + (t - 5) * 8192);
-    float4 bv2[4];
+    bn_f32x4 bv2[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bv2[g] = *reinterpret_cast<const float4 *>(bias12 + 64 + 32 * wc + 8 * g + 4 * lh);
+    for (int g = 0; g < 4; ++g) bv2[g] = *reinterpret_cast<const bn_f32x4 *>(bias12 + 64 + 32 * wc + 8 * g + 4 * lh);
     __syncthreads();   // every wave is done with T1, the tap buffers and b2
     BN_STAMP(6);
     // W3 (256 x 64) -> region A: 32 pieces, wave w stages pieces w + 8j
@@ -326,10 +331,10 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
         char *T2 = smem + BN_D;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            uint2 pk;
+            bn_u32x2 pk;
             pk.x = bn_pk_relu(bn_pk_bf16(acc2[4 * g + 0] + bv2[g].x, acc2[4 * g + 1] + bv2[g].y));
             pk.y = bn_pk_relu(bn_pk_bf16(acc2[4 * g + 2] + bv2[g].z, acc2[4 * g + 3] + bv2[g].w));
-            *reinterpret_cast<uint2 *>(T2 + pB * BN_ROWB + (((4 * wc + g) ^ ((pB >> 1) & 7)) << 4) + 8 * lh) = pk;
+            *reinterpret_cast<bn_u32x2 *>(T2 + pB * BN_ROWB + (((4 * wc + g) ^ ((pB >> 1) & 7)) << 4) + 8 * lh) = pk;
         }
     }
     // this thread's two 16-B pieces of a quarter's image in global memory
@@ -378,8 +383,8 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c_local = 32 * wc + 8 * g + 4 * lh;
-            const float4 bv = *reinterpret_cast<const float4 *>(bias3 + 64 * q + c_local);
-            uint2 pk;
+            const bn_f32x4 bv = *reinterpret_cast<const bn_f32x4 *>(bias3 + 64 * q + c_local);
+            bn_u32x2 pk;
             pk.x = bn_pk_bf16(acc3[4 * g + 0] + bv.x, acc3[4 * g + 1] + bv.y);
             pk.y = bn_pk_bf16(acc3[4 * g + 2] + bv.z, acc3[4 * g + 3] + bv.w);
             if constexpr (MODE == 2) {   // + bf16(Wd . x + bd), ReLU: the final value goes into the image
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
                 pk.x = bn_pk_relu(bn_pk_bf16(s0.x, s0.y));
                 pk.y = bn_pk_relu(bn_pk_bf16(s1.x, s1.y));
             }
-            *reinterpret_cast<uint2 *>(E + pB * BN_ES + c_local * 2) = pk;
+            *reinterpret_cast<bn_u32x2 *>(E + pB * BN_ES + c_local * 2) = pk;
         }
         BN_BAR_RAW();   // raw barriers in this loop: __syncthreads() would wait for the previous quarter's stores to COMPLETE (vmcnt 0)
         if (q == 1) BN_STAMP(14);
