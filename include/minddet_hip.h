@@ -236,6 +236,9 @@ int md_conv2d_set_stream_rounds(int rounds);
 /* Tools only: workgroups per CU the grid of conv1x1_stream_kernel is sized for (default 2) and its cache-policy bits
  * (1 = activation DMA nt, 2 = residual DMA nt, 4 = stores nt; default 6). */
 int md_conv2d_set_stream_tune(int wgs_per_cu, int cache_bits);
+/* Tools only: the persistent form of the 256x256 ping-pong kernel is the dispatcher's choice for eligible layers with K >= k (default
+ * 2304).  Returns the previous value. */
+int md_conv2d_set_pers_min_k(int k);
 
 /* ------------------------------------------------------------------------------------------
  * Streaming NHWC bf16 helpers between convs

@@ -802,6 +802,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
 #define MD_ERR_UNSUPPORTED_STREAM 101
 static int g_stream_rounds = 1;   // workgroup rounds the pixel range is cut into (tools only: md_conv2d_set_stream_rounds)
 static int g_stream_wgs_per_cu = 2, g_stream_tune = 6;   // tools only: md_conv2d_set_stream_tune
+static int g_pers_min_k = 2304;   // the persistent form of the ping-pong kernel is the auto choice from this K on (tools: md_conv2d_set_pers_min_k)
 template <int K, int CB>
 static int launch_conv1x1_stream_t(ConvArgs &a, hipStream_t s) {
     constexpr int NR = K == 512 ? 2 : (K == 128 ? 4 : 3);
@@ -1089,8 +1090,12 @@ struct KWalk { int tap, kh, kw, cc0; };
 
 // MF 0: v_mfma_f32_32x32x16_bf16, MF 1: v_mfma_f32_16x16x32_bf16 (same LDS image, reads and cycles per flop; the chip holds a
 // different clock on the two shapes under load -- MI355X_MICROARCH.md DVFS item 7 -- so both are built and the faster kept).
-template <int ABL, int MF = 0, int GEN = 1, bool HEAD = false>  // GEN as in conv_igemm_kernel; HEAD: fused 1x1 head; ABL 0: product; timing ablations (wrong results): 1 no in-loop staging, 2 no output stores, 4 stamps
+// PERS (GEN 0 / 2, no residual, plain or concat output): PERSISTENT form -- one workgroup per CU walks over several pixel tiles; the seven
+// prologue half tiles of the NEXT tile are requested before the current tile's epilogue, which runs barrier-free through wave-private
+// 2.5-KiB LDS slabs (the staging buffers stay free for the DMA stream) and leaves as buffer stores.
+template <int ABL, int MF = 0, int GEN = 1, bool HEAD = false, bool PERS = false>  // GEN as in conv_igemm_kernel; HEAD: fused 1x1 head; ABL 0: product; timing ablations (wrong results): 1 no in-loop staging, 2 no output stores, 4 stamps
 __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
+    static_assert(!PERS || (!HEAD && ABL == 0 && GEN != 1), "the persistent form has the plain epilogues only");
     constexpr int CT = 256, PT = 256, NT = 512;
     constexpr int EP_STRIDE = CT * 2 + 16;
     constexpr unsigned OOR = 0x80000000u;
@@ -1102,15 +1107,18 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int ct = slot % a.n_ctiles, pt = xcd * a.pt_per_xcd + slot / a.n_ctiles;
-    if (pt >= a.n_ptiles) return;
-    const int cout0 = ct * CT, pix0 = pt * PT;
+    const int ct = slot % a.n_ctiles;
+    int ptl = slot / a.n_ctiles;                                        // pixel tile inside the XCD's range
+    const int pstep = PERS ? (int)(gridDim.x >> 3) / a.n_ctiles : 0;    // PERS: the workgroups of an (XCD, cout tile) stride through the range
+    if (ptl >= a.pt_per_xcd || xcd * a.pt_per_xcd + ptl >= a.n_ptiles) return;
+    const int cout0 = ct * CT;
+    int pix0 = (xcd * a.pt_per_xcd + ptl) * PT;
     const int n_taps = a.kh * a.kw, nk = a.Kpad / BK;
     unsigned long long clk_start = 0;
     if (ABL == 4) clk_start = __builtin_readcyclecounter();
     // bias: requested now, parked in LDS past the epilogue image after the prologue wait (see conv_igemm_kernel)
     const float bias_early = tid < CT ? a.bias[cout0 + tid] : 0.f;
-    float *bias_lds = reinterpret_cast<float *>(smem + PT * EP_STRIDE);
+    float *bias_lds = reinterpret_cast<float *>(smem + (PERS ? 8 * 128 * ROWB : PT * EP_STRIDE));   // PERS: right behind the 128 KiB of staging buffers
 
     __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
@@ -1122,6 +1130,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     const int a_half = 64 * a.Kpad * 2, a_pass = 128 * a.Kpad * 2;
     int p_base[4];       // [hB * 2 + i]: byte offset of (n, hi0, wi0, chunk) of the staged pixel row
     unsigned p_taps[4];  // tap-validity bits (0 past M)
+    auto setup_tile = [&]() {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int hB = q >> 1, i = q & 1;
@@ -1141,6 +1150,8 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
             p_taps[q] = bits;
         }
     }
+    };
+    setup_tile();
     auto walk_next = [&](KWalk &w) {
         if (a.korder == 0) {
             w.cc0 += 8;
@@ -1178,6 +1189,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 
     f32x16 acc[MF ? 1 : 4][MF ? 1 : 2];
     f32x4 acc4[MF ? 8 : 1][MF ? 4 : 1];  // MF 1: [16-row fragment of the wave's 128 couts][16-pixel fragment of its 64 pixels]
+    auto zero_acc = [&]() {
     if constexpr (MF == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1191,6 +1203,8 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc4[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    };
+    zero_acc();
 
     const int lr = lane & 31, lh = lane >> 5;
     const int l16 = lane & 15, lq = lane >> 4;
@@ -1261,14 +1275,25 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (lds_void *)(smem + W2_OFF + wave * 1024), 16, row * 512 + ((phys ^ row) & 31) * 16, 0, 0, 0);
     }
     // ---- prologue: tile 0 and the A0/B0/B1 halves of tile 1 (seven half tiles)
-    KWalk w0 = {0, 0, 0, 0}, w1 = w0;
-    walk_next(w1);
-    KWalk w2 = w1;
-    walk_next(w2);
-    stage_A(0, 0, H_A0); stage_B(0, 0, H_B0, w0); stage_B(0, 1, H_B1, w0); stage_A(0, 1, H_A1);
-    stage_A(1, 0, H_A0); stage_B(1, 0, H_B0, w1); stage_B(1, 1, H_B1, w1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // also retires the (older) bias load
-    if (tid < CT) bias_lds[tid] = bias_early;         // read in the epilogue, hundreds of barriers later
+    KWalk w2 = {0, 0, 0, 0};
+    auto issue_prologue = [&]() {
+        KWalk w0 = {0, 0, 0, 0}, w1 = w0;
+        walk_next(w1);
+        w2 = w1;
+        walk_next(w2);
+        stage_A(0, 0, H_A0); stage_B(0, 0, H_B0, w0); stage_B(0, 1, H_B1, w0); stage_A(0, 1, H_A1);
+        stage_A(1, 0, H_A0); stage_B(1, 0, H_B0, w1); stage_B(1, 1, H_B1, w1);
+    };
+    issue_prologue();
+    bool first_tile = true;
+    for (;;) {   // one pass unless PERS
+    if (!PERS || first_tile) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // also retires the (older) bias load
+        if (tid < CT) bias_lds[tid] = bias_early;         // read in the epilogue, hundreds of barriers later
+    } else {
+        // behind the seven prologue half tiles (14 DMAs, the first 6 needed now) sit the 16 stores of the previous tile's epilogue
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs half a phase behind group 0
     __builtin_amdgcn_sched_barrier(0);
@@ -1321,6 +1346,68 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 #undef PP_MFMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero-fill DMAs of the two tiles past the end
     __syncthreads();
+    if constexpr (PERS) {
+        // ---- persistent form: request the next tile's prologue NOW (every wave is past its last fragment read), then run this tile's
+        // epilogue out of the registers through the wave's private slab -- builtin vector types only (see conv1x1_stream_kernel)
+        const int pix_cur = pix0;
+        ptl += pstep;
+        const bool more = ptl < a.pt_per_xcd && xcd * a.pt_per_xcd + ptl < a.n_ptiles;
+        if (more) {
+            pix0 = (xcd * a.pt_per_xcd + ptl) * PT;
+            setup_tile();
+            issue_prologue();
+        }
+        char *slab = smem + 8 * 128 * ROWB + CT * 4 + wave * 2560;
+        const long long rem = ((long long)a.M - pix_cur) * a.Ctot * 2 - (a.c_off + cout0) * 2;
+        __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + (size_t)pix_cur * a.Ctot + a.c_off + cout0), 0,
+                                                                        (int)(rem > 0x7fffffffLL ? 0x7fffffffLL : rem), 0x00020000);
+        const int e_px = lane >> 2, e_ch = lane & 3;
+        const int v_io = ((wc * 64 + e_px) * a.Ctot + wr * 128 + e_ch * 8) * 2, row_b = a.Ctot * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // block = couts wr * 128 + 32 i .., pixels wc * 64 + 32 j ..
+                if constexpr (MF == 0) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + wr * 128 + i * 32 + 8 * g + 4 * lh);
+                        f32x2 s01 = (f32x2){acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
+                        f32x2 s23 = (f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
+                        if (GEN == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
+                        u32x2 pk;
+                        pk.x = pk_bf16(s01.x, s01.y);
+                        pk.y = pk_bf16(s23.x, s23.y);
+                        if (GEN == 0 && a.relu == 1) { pk.x = pk_relu_bf16(pk.x); pk.y = pk_relu_bf16(pk.y); }
+                        *reinterpret_cast<u32x2 *>(slab + lr * 80 + 16 * g + 8 * lh) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + wr * 128 + (2 * i + ii) * 16 + 4 * lq);
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const f32x4 v = acc4[2 * i + ii][2 * j + jj];
+                            float v0 = v[0] + bv.x, v1 = v[1] + bv.y, v2 = v[2] + bv.z, v3 = v[3] + bv.w;
+                            if (GEN == 0 && a.relu == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                            else if (GEN == 2) { v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3); }
+                            u32x2 pk;
+                            pk.x = pk_bf16(v0, v1);
+                            pk.y = pk_bf16(v2, v3);
+                            *reinterpret_cast<u32x2 *>(slab + (jj * 16 + l16) * 80 + (ii * 16 + 4 * lq) * 2) = pk;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(slab + (e_px + 16 * it) * 80 + e_ch * 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, v_io + (j * 32 + 16 * it) * row_b, i * 64, 2);
+                }
+            }
+        if (!more) return;
+        zero_acc();
+        first_tile = false;
+        continue;
+    }
 
     // ---- epilogue: bias (+act) -> bf16x4 -> LDS [pixel][cout] -> (+residual, ReLU) -> 16-B NHWC stores
     constexpr int CPP = CT / 8, EP_ITERS = PT * CPP / NT;
@@ -1449,6 +1536,8 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
             dbg[13] = clk0 - clk_start; dbg[14] = clk_end - clk1;  // prologue / epilogue cycles
         }
     }
+    return;
+    }   // tile loop
 }
 
 // The MFMA shape of the ping-pong kernel per layer (r02, tools/pp_mf_ab.py, batch 60, same box, bit-identical results): the chip
@@ -1474,6 +1563,21 @@ static int launch_conv_pingpong_head(ConvArgs &a, hipStream_t s) {
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
     const int lds = 256 * (256 * 2 + 16) + 256 * 4 + 16 * 256 * 2;  // epilogue image + bias + head weights
     return pingpong_wants_16x16(a) ? launch_conv_pingpong_head_mf<1>(a, s, blocks, lds) : launch_conv_pingpong_head_mf<0>(a, s, blocks, lds);
+}
+
+// the persistent form: one workgroup per CU, S = 32 / n_ctiles workgroups per (XCD, cout tile) stride through the XCD's pixel range
+template <int MF>
+static int launch_conv_pingpong_pers(ConvArgs &a, hipStream_t s) {
+    ++g_launch_count;
+    g_last_kernel = MD_CONV_KERNEL_PINGPONG;
+    a.n_ctiles = a.Cout / 256;
+    a.n_ptiles = (a.M + 255) / 256;
+    a.pt_per_xcd = (a.n_ptiles + 7) / 8;
+    const int lds = 8 * 128 * ROWB + 256 * 4 + 8 * 2560;   // staging buffers + bias + eight wave-private slabs
+    auto k = a.relu == 2 ? conv_pingpong_kernel<0, MF, 2, false, true> : conv_pingpong_kernel<0, MF, 0, false, true>;
+    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+    hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
 template <int ABL = 0, int MF = 0>
@@ -1517,6 +1621,12 @@ extern "C" long long md_conv2d_set_chunk_limit(long long bytes) {
 extern "C" int md_conv2d_set_stream_rounds(int rounds) {   // tools only: workgroup rounds of conv1x1_stream_kernel (default 1)
     const int old = g_stream_rounds;
     g_stream_rounds = rounds >= 1 && rounds <= 64 ? rounds : 1;
+    return old;
+}
+
+extern "C" int md_conv2d_set_pers_min_k(int k) {   // tools only
+    const int old = g_pers_min_k;
+    g_pers_min_k = k >= 1 ? k : 2304;
     return old;
 }
 
@@ -1602,7 +1712,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     a.res_up = at->res_upsample != 0 && params[3] != nullptr;
     // one LDS staging buffer by default: measured r01 (tools/conv_ab.py), 4 resident workgroups per CU with a serial
     // DMA -> MFMA loop beat 2 double-buffered ones on every benchmark layer (+8...43 %); variant 2 keeps the double buffer
-    a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 25 || at->variant == 30 || at->variant == 31;
+    a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 25 || at->variant == 30 || at->variant == 31 || at->variant == 32 || at->variant == 33;
     a.stamp = 0; a.dbg = nullptr;
     if ((at->variant >= 17 && at->variant <= 19) || at->variant == 25) {
         // timing ablations / stamp builds: wrong results by construction, so not part of the product library
@@ -1673,7 +1783,8 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     // 256->1024 + residual -0.40 ms/step (5 launches), 512->256 -0.12, 512->2048 + residual -0.09; 128->512 + residual +0.15 (stays on
     // the 128x128 kernel); the 128-cout forms lose 2-15 % -- and every workgroup gets at least 8 tiles to stream past its weights
     const bool no_stream = variant == 31;   // 31 = the dispatcher's choice without conv1x1_stream_kernel (A/B)
-    if (no_stream) variant = 0;
+    const bool no_pers = variant == 33;     // 33 = the dispatcher's choice without the persistent form of the ping-pong kernel (A/B)
+    if (no_stream || no_pers) variant = 0;
     const bool stream_auto = variant == 0 && !no_stream && !head && dma_ok && stream1x1_takes(a) && a.Cout % 256 == 0 && a.Cin != 128 &&
                              (M + 31) / 32 * (a.Cout / (a.Cin == 512 ? 128 : 256)) >= 4096;
     if ((variant == 30 || stream_auto) && !head) {
@@ -1722,6 +1833,17 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
                               cout_pad % 64 == 0 && !a.res_up &&
                               a.Ho == a.H && a.Wo == a.W && (!pp_ok || pp_ragged) && halo_fits;
     if (halo64_first) return launch_conv3x3_halo<64, true>(a, s);
+    // the persistent form of the ping-pong kernel (no residual, plain / concat output, the cout tiles divide a 32-CU XCD, more than one
+    // round of tiles): auto for the long-K layers (r02 tools/pp_pers_ab.py, batch 60, bit-identical: 3x3 256->256 +3.2...4.4 %, 3x3 512->512
+    // +4.2 %; the K = 1024 1x1 layers lose 4-5 %: behind a tile's prologue DMAs sit the previous tile's stores, and the loop's first counted
+    // wait then covers their write latency -- 1 / 16 of such a tile's K loop); variant 32 forces it, 33 = auto without it
+    {
+        const bool cat_only_p = !a.adv || (a.os == 1 && a.oy == 0 && a.ox == 0 && a.Ho == a.Hf && a.Wo == a.Wf);
+        const bool pers_ok = fast && dma_ok && a.Cout % 256 == 0 && !a.res && !a.res_up && cat_only_p && 32 % (a.Cout / 256) == 0 && pp_blocks > 256;
+        const bool pers_auto = variant == 0 && !no_pers && pp_ok && pers_ok && a.Kpad >= g_pers_min_k;
+        if ((variant == 32 || pers_auto) && pers_ok) return pingpong_wants_16x16(a) ? launch_conv_pingpong_pers<1>(a, s) : launch_conv_pingpong_pers<0>(a, s);
+        if (variant == 32) variant = 0;
+    }
     if (variant == 0 && pp_ok) return pingpong_wants_16x16(a) ? launch_conv_pingpong<0, 1>(a, s) : launch_conv_pingpong<0>(a, s);
     if (halo_ok && !a.res_up && variant == 11) return launch_conv3x3_halo<128, false>(a, s);  // superseded by the paths around it
     // 64-cout tiles of the halo kernel at four workgroups per CU (variant 27; auto for Cout <= 64)

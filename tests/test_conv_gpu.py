@@ -638,3 +638,44 @@ def test_conv1x1_stream_kernel_random_shapes_against_the_tile_kernel():
             lib.md_conv2d_set_stream_rounds(old)
         assert lib.md_conv2d_last_kernel() == 8, (case, cin, cout)
         assert torch.equal(got, ref), (case, cin, cout, n, h, w, kind, act, rounds)
+
+
+@pytest.mark.parametrize("cfg", [
+    # name, N, H, W, Cin, Cout, k, act, concat output
+    ("3x3_256_many_tiles", 6, 100, 168, 256, 256, 3, "relu", False),
+    ("3x3_512_two_cout_tiles_ragged", 12, 61, 57, 512, 512, 3, "relu", False),
+    ("3x3_256_silu_concat", 12, 80, 80, 256, 256, 3, "silu", True),
+    ("1x1_1024_256_none", 20, 50, 84, 1024, 256, 1, "none", False),
+    ("16x16_mfma_form", 12, 200, 168, 256, 256, 3, "relu", False),      # M >= 400 000 pixels
+    ("barely_two_rounds", 3, 150, 150, 256, 256, 3, "relu", False),     # 264 tiles on 256 workgroups
+], ids=lambda c: c[0])
+def test_pingpong_persistent_form_is_bit_identical(cfg):
+    """The persistent form of the ping-pong kernel (variant 32: one workgroup per CU walks over several pixel tiles, next tile's
+    prologue requested before the epilogue, slab epilogue) against the one-tile-per-workgroup form (variants 15 / 22): same main loop, same
+    rounding -> bit for bit; partial last tiles, two cout tiles, SiLU, concat outputs, both MFMA shapes."""
+    from minddet_amd import _lib, nn_ops
+
+    name, N, H, W, Cin, Cout, k, act, cat = cfg
+    g = torch.Generator().manual_seed(len(name) + Cin)
+    wt = torch.randn((Cout, Cin, k, k), generator=g) * (2.0 / (k * k * Cin)) ** 0.5
+    pc = nn_ops.pack_conv(wt, bias=torch.randn((Cout,), generator=g) * 0.1, stride=1, pad=k // 2,
+                          relu={"none": 0, "relu": 1, "silu": "silu"}[act]).to(DEV)
+    x = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16).to(DEV)
+    # the one-tile-per-workgroup form with the MFMA shape the persistent launcher picks for this layer (15: 32x32x16, 22: 16x16x32)
+    ref = nn_ops.conv2d(x, pc, variant=22 if (k == 3 and k * k * Cin >= 2304 and N * H * W >= 400000) else 15)
+    assert _lib.lib().md_conv2d_last_kernel() == 1
+    got = nn_ops.conv2d(x, pc, variant=32)
+    assert _lib.lib().md_conv2d_last_kernel() == 1
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    if cat:
+        buf = torch.full((N, H, W, Cout + 72), 3.0, dtype=torch.bfloat16, device=DEV)
+        nn_ops.conv2d(x, pc, variant=32, out=buf, c_off=64)
+        assert torch.equal(buf[..., 64:64 + Cout], ref) and (buf[..., :64] == 3.0).all() and (buf[..., 64 + Cout:] == 3.0).all()
+    # a grid of at most one round stays on the one-tile-per-workgroup form
+    xs = x[:1, :32, :32].contiguous()
+    assert torch.equal(nn_ops.conv2d(xs, pc, variant=32), nn_ops.conv2d(xs, pc, variant=33))
+    # spot check against fp32 on the first image
+    y = F.conv2d(x[:1].float().cpu().permute(0, 3, 1, 2), wt.to(torch.bfloat16).float(), pc.bias[:Cout].float().cpu(), padding=k // 2).permute(0, 2, 3, 1)
+    y = F.silu(y) if act == "silu" else (torch.relu(y) if act == "relu" else y)
+    assert ((ref[:1].float().cpu() - y).abs() <= 2e-2 * y.abs() + 2e-2 * y.pow(2).mean().sqrt()).all()
