@@ -1361,48 +1361,63 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         const long long rem = ((long long)a.M - pix_cur) * a.Ctot * 2 - (a.c_off + cout0) * 2;
         __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + (size_t)pix_cur * a.Ctot + a.c_off + cout0), 0,
                                                                         (int)(rem > 0x7fffffffLL ? 0x7fffffffLL : rem), 0x00020000);
-        const int e_px = lane >> 2, e_ch = lane & 3;
+        // a slab holds 16 pixels x 64 output channels (144-B rows): its read-out is 8 lanes per pixel = one whole 128-B line per pixel and
+        // store instruction.  (32 x 32 slabs stored 64-B half lines: rocprofv3 FETCH_SIZE showed 15 % more HBM reads -- the L2 fills a
+        // partially written line first.)
+        const int e_px = lane >> 3, e_ch = lane & 7;
         const int v_io = ((wc * 64 + e_px) * a.Ctot + wr * 128 + e_ch * 8) * 2, row_b = a.Ctot * 2;
+        auto flush_slab = [&](int px0, int c0) {   // pixels px0 .. px0 + 15 of the wave's 64, couts c0 .. c0 + 63 of its 128
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {   // block = couts wr * 128 + 32 i .., pixels wc * 64 + 32 j ..
-                if constexpr (MF == 0) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + wr * 128 + i * 32 + 8 * g + 4 * lh);
-                        f32x2 s01 = (f32x2){acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
-                        f32x2 s23 = (f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
-                        if (GEN == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
-                        u32x2 pk;
-                        pk.x = pk_bf16(s01.x, s01.y);
-                        pk.y = pk_bf16(s23.x, s23.y);
-                        if (GEN == 0 && a.relu == 1) { pk.x = pk_relu_bf16(pk.x); pk.y = pk_relu_bf16(pk.y); }
-                        *reinterpret_cast<u32x2 *>(slab + lr * 80 + 16 * g + 8 * lh) = pk;
-                    }
-                } else {
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + wr * 128 + (2 * i + ii) * 16 + 4 * lq);
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const f32x4 v = acc4[2 * i + ii][2 * j + jj];
-                            float v0 = v[0] + bv.x, v1 = v[1] + bv.y, v2 = v[2] + bv.z, v3 = v[3] + bv.w;
-                            if (GEN == 0 && a.relu == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                            else if (GEN == 2) { v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3); }
-                            u32x2 pk;
-                            pk.x = pk_bf16(v0, v1);
-                            pk.y = pk_bf16(v2, v3);
-                            *reinterpret_cast<u32x2 *>(slab + (jj * 16 + l16) * 80 + (ii * 16 + 4 * lq) * 2) = pk;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const u32x4 v = *reinterpret_cast<const u32x4 *>(slab + (e_px + 16 * it) * 80 + e_ch * 16);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, v_io + (j * 32 + 16 * it) * row_b, i * 64, 2);
-                }
+            for (int it = 0; it < 2; ++it) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(slab + (e_px + 8 * it) * 144 + e_ch * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, v_io + (px0 + 8 * it) * row_b, c0 * 2, 2);
             }
+        };
+        if constexpr (MF == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {   // 32 x 32 accumulator tiles (ip * 2, ip * 2 + 1) x j, pixel half h (lanes lr >> 4 == h)
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii) {
+                            const int i = 2 * ip + ii;
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + wr * 128 + i * 32 + 8 * g + 4 * lh);
+                                f32x2 s01 = (f32x2){acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
+                                f32x2 s23 = (f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
+                                if (GEN == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }
+                                u32x2 pk;
+                                pk.x = pk_bf16(s01.x, s01.y);
+                                pk.y = pk_bf16(s23.x, s23.y);
+                                if (GEN == 0 && a.relu == 1) { pk.x = pk_relu_bf16(pk.x); pk.y = pk_relu_bf16(pk.y); }
+                                if ((lr >> 4) == h) *reinterpret_cast<u32x2 *>(slab + (lr & 15) * 144 + ii * 64 + 16 * g + 8 * lh) = pk;
+                            }
+                        }
+                        flush_slab(j * 32 + h * 16, ip * 64);
+                    }
+        } else {
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {       // 16 x 16 accumulator tiles (4 q .. 4 q + 3) x j4
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + wr * 128 + (4 * q + ii) * 16 + 4 * lq);
+                        const f32x4 v = acc4[4 * q + ii][j4];
+                        float v0 = v[0] + bv.x, v1 = v[1] + bv.y, v2 = v[2] + bv.z, v3 = v[3] + bv.w;
+                        if (GEN == 0 && a.relu == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                        else if (GEN == 2) { v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3); }
+                        u32x2 pk;
+                        pk.x = pk_bf16(v0, v1);
+                        pk.y = pk_bf16(v2, v3);
+                        *reinterpret_cast<u32x2 *>(slab + l16 * 144 + (ii * 16 + 4 * lq) * 2) = pk;
+                    }
+                    flush_slab(j4 * 16, q * 64);
+                }
+        }
         if (!more) return;
         zero_acc();
         first_tile = false;
