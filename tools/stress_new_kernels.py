@@ -1,0 +1,41 @@
+"""Race hunt: the persistent ping-pong form (variant 32), the stream kernel (30) and md_stem_conv run many times on the same operands;
+every output must equal the first one and the reference kernel's bit for bit.  python tools/stress_new_kernels.py [reps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from minddet_amd import nn_ops
+
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+dev = "cuda:0"
+g = torch.Generator().manual_seed(0)
+bad = 0
+CASES = [("pers 3x3 256 b30 P2", 32, 15, (30, 200, 336, 256), 256, 3, False), ("pers 3x3 256 @50x84", 32, 15, (60, 50, 84, 256), 256, 3, False),
+         ("pers 3x3 512 @25x42", 32, 15, (60, 25, 42, 512), 512, 3, False), ("pers 1x1 1024->256", 32, 15, (60, 50, 84, 1024), 256, 1, False),
+         ("stream 256->1024 +res", 30, 20, (60, 50, 84, 256), 1024, 1, True), ("stream 512->256", 30, 20, (60, 100, 168, 512), 256, 1, False),
+         ("stream 256->256 +res", 30, 20, (60, 100, 168, 256), 256, 1, True)]
+for name, v, vref, xs, cout, k, res in CASES:
+    cin = xs[3]
+    w = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (k * k * cin)) ** 0.5
+    pc = nn_ops.pack_conv(w, bias=torch.randn((cout,), generator=g) * 0.1, stride=1, pad=k // 2, relu=True).to(dev)
+    x = torch.randn(xs, generator=g).to(torch.bfloat16).to(dev)
+    r = torch.randn(xs[:3] + (cout,), generator=g).to(torch.bfloat16).to(dev) if res else None
+    if v == 32 and k == 3 and xs[0] * xs[1] * xs[2] >= 400000:
+        vref = 22
+    ref = nn_ops.conv2d(x, pc, residual=r, variant=vref)
+    y = torch.empty_like(ref)
+    n_bad = 0
+    for i in range(REPS):
+        y.fill_(7.0)
+        nn_ops.conv2d(x, pc, residual=r, variant=v, out=y)
+        if not torch.equal(y, ref):
+            n_bad += 1
+    bad += n_bad
+    print(f"{name}: {REPS} runs, {n_bad} mismatches", flush=True)
+ps = nn_ops.pack_stem_conv(torch.randn((32, 3, 6, 6), generator=g) * 0.1, act="silu").to(dev)
+x4 = nn_ops.to_stem_layout(torch.randn((32, 640, 640, 8), generator=g).to(torch.bfloat16).to(dev))
+ref = nn_ops.stem_conv(x4, ps)
+n_bad = sum(0 if torch.equal(nn_ops.stem_conv(x4, ps), ref) else 1 for _ in range(REPS))
+bad += n_bad
+print(f"stem_conv 6x6 b32: {REPS} runs, {n_bad} mismatches", flush=True)
+print("TOTAL MISMATCHES", bad)
+sys.exit(1 if bad else 0)
