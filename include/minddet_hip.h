@@ -239,6 +239,9 @@ int md_conv2d_set_stream_tune(int wgs_per_cu, int cache_bits);
 /* Tools only: the persistent form of the 256x256 ping-pong kernel is the dispatcher's choice for eligible layers with K >= k (default
  * 2304).  Returns the previous value. */
 int md_conv2d_set_pers_min_k(int k);
+/* Tools only: md_conv1x1_dual runs on the 256x256 ping-pong kernel when its concatenated K is >= k (default 768), Cout % 256 == 0 and
+ * there is no residual tensor; otherwise on the 128x128 kernel.  Returns the previous value. */
+int md_conv2d_set_dual_pp_min_k(int k);
 
 /* ------------------------------------------------------------------------------------------
  * Streaming NHWC bf16 helpers between convs

@@ -539,8 +539,15 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
 }
 
 
+static int launch_conv_dual_pingpong(ConvArgs &a, hipStream_t s);   // defined behind the ping-pong kernel
+static int g_dual_pp_min_k = 768;   // md_conv1x1_dual runs on the ping-pong kernel from this K on (tools: md_conv2d_set_dual_pp_min_k)
+
 // 128 x 128 single-buffer kernel on the K-concatenation of two inputs (md_conv1x1_dual)
 static int launch_conv_dual(ConvArgs &a, hipStream_t s) {
+    // long-K, MFMA-bound forms (768 -> 1024, 1536 -> 2048 of the ResNet-50 stages 3 / 4): the 256x256 ping-pong kernel reading its K tiles
+    // past nk_a from the second tensor
+    if (a.Cout % 256 == 0 && a.Kpad >= g_dual_pp_min_k && !a.res && (long long)(a.M + 255) / 256 * (a.Cout / 256) >= 256)
+        return launch_conv_dual_pingpong(a, s);
     constexpr int CT = 128, PT = 128;
     ++g_launch_count;
     g_last_kernel = MD_CONV_KERNEL_IGEMM_128;
@@ -1122,6 +1129,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 
     __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void *)(a.x2 ? a.x2 : a.x), 0, a.x2 ? a.x2_bytes : 0u, 0x00020000);
 
     // ---- staging map: one wave instruction = 8 rows x 128 B; a half tile = 2 instructions per wave (rows srow, srow+64)
     const int srow = wave * 8 + (lane >> 3);
@@ -1130,12 +1138,18 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     const int a_half = 64 * a.Kpad * 2, a_pass = 128 * a.Kpad * 2;
     int p_base[4];       // [hB * 2 + i]: byte offset of (n, hi0, wi0, chunk) of the staged pixel row
     unsigned p_taps[4];  // tap-validity bits (0 past M)
+    unsigned p_base2[4]; // DUAL (a.x2 != null: md_conv1x1_dual): the row's pixel in the second tensor, sampled with a.stride2 (OOR past M)
     auto setup_tile = [&]() {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int hB = q >> 1, i = q & 1;
         const int m = pix0 + (i * 2 + (wave >> 2)) * 64 + hB * 32 + (wave & 3) * 8 + (lane >> 3);
-        p_base[q] = 0; p_taps[q] = 0u;
+        p_base[q] = 0; p_taps[q] = 0u; p_base2[q] = OOR;
+        if (a.x2 && m < a.M) {
+            const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
+            const int ho = r / a.Wo, wo = r - ho * a.Wo;
+            p_base2[q] = (unsigned)((((n * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2) * a.Xs2) * 2 + chunk * 16);
+        }
         if (a.pointwise) {
             if (m < a.M) { p_base[q] = m * a.Xs * 2 + chunk * 16; p_taps[q] = 1u; }
         } else if (m < a.M) {
@@ -1179,6 +1193,14 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         if (ABL == 1 && kt >= 2) return;
         char *dst = smem + ((kt & 1) * 4 + hbuf) * PP_HALF + wave * (8 * ROWB);
         const unsigned dead = (unsigned)((nk - 1 - kt) >> 31) << 31;
+        if (a.x2 && kt >= a.nk_a) {   // DUAL: K tiles past nk_a are 64-channel chunks of the second tensor's (strided) pixel
+            const int ktc = kt < nk ? kt : nk - 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (lds_void *)(dst + i * 64 * ROWB), 16, (int)(p_base2[hB * 2 + i] | dead),
+                                                         (ktc - a.nk_a) * (BK * 2), 0, 0);
+            return;
+        }
         const int soff = ((w.kh * a.W + w.kw) * a.Xs + w.cc0 * 8) * 2;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1595,6 +1617,21 @@ static int launch_conv_pingpong_pers(ConvArgs &a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
+static int launch_conv_dual_pingpong(ConvArgs &a, hipStream_t s) {
+    ++g_launch_count;
+    g_last_kernel = MD_CONV_KERNEL_PINGPONG;
+    a.n_ctiles = a.Cout / 256;
+    a.n_ptiles = (a.M + 255) / 256;
+    a.pt_per_xcd = (a.n_ptiles + 7) / 8;
+    const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
+    if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
+    const int lds = 256 * (256 * 2 + 16) + 256 * 4;
+    auto k = conv_pingpong_kernel<0, 0, 0>;
+    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
+}
+
 template <int ABL = 0, int MF = 0>
 static int launch_conv_pingpong(ConvArgs &a, hipStream_t s) {
     ++g_launch_count;
@@ -1636,6 +1673,12 @@ extern "C" long long md_conv2d_set_chunk_limit(long long bytes) {
 extern "C" int md_conv2d_set_stream_rounds(int rounds) {   // tools only: workgroup rounds of conv1x1_stream_kernel (default 1)
     const int old = g_stream_rounds;
     g_stream_rounds = rounds >= 1 && rounds <= 64 ? rounds : 1;
+    return old;
+}
+
+extern "C" int md_conv2d_set_dual_pp_min_k(int k) {   // tools only
+    const int old = g_dual_pp_min_k;
+    g_dual_pp_min_k = k >= 128 ? k : 768;
     return old;
 }
 
@@ -1704,7 +1747,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
         }
     }
     int variant_override = -1;
-    ConvArgs a;
+    ConvArgs a = {};   // (x2 == null: not a dual launch)
     a.x = (const uint16_t *)params[0];
     a.w = (const uint16_t *)params[1];
     a.bias = (const float *)params[2];

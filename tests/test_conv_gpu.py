@@ -679,3 +679,31 @@ def test_pingpong_persistent_form_is_bit_identical(cfg):
     y = F.conv2d(x[:1].float().cpu().permute(0, 3, 1, 2), wt.to(torch.bfloat16).float(), pc.bias[:Cout].float().cpu(), padding=k // 2).permute(0, 2, 3, 1)
     y = F.silu(y) if act == "silu" else (torch.relu(y) if act == "relu" else y)
     assert ((ref[:1].float().cpu() - y).abs() <= 2e-2 * y.abs() + 2e-2 * y.pow(2).mean().sqrt()).all()
+
+
+@pytest.mark.parametrize("cfg", [("stage3", 24, 50, 84, 256, 512, 1024, 2), ("stage4_ragged", 48, 25, 41, 512, 1024, 2048, 2),
+                                 ("stride1_long_k", 10, 61, 59, 256, 512, 512, 1)], ids=lambda c: c[0])
+def test_conv1x1_dual_on_the_pingpong_kernel(cfg):
+    """The long-K forms of md_conv1x1_dual (K = Ca + Cb >= 768, Cout % 256 == 0) run on the 256x256 ping-pong kernel, its K tiles past Ca
+    staged from the second (strided) tensor: bit-identical to the 128x128 kernel's result (same K order, one rounding), ragged last tile."""
+    from minddet_amd import _lib, nn_ops
+
+    name, N, Ho, Wo, Ca, Cb, Cout, s = cfg
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(len(name) + Ca)
+    Hb, Wb = (Ho - 1) * s + 1, (Wo - 1) * s + 1
+    pc3 = nn_ops.pack_conv(torch.randn((Cout, Ca, 1, 1), generator=g) * (1.0 / Ca) ** 0.5, bias=torch.randn((Cout,), generator=g) * 0.1, relu=True).to(DEV)
+    pd = nn_ops.pack_conv(torch.randn((Cout, Cb, 1, 1), generator=g) * (1.0 / Cb) ** 0.5, bias=torch.randn((Cout,), generator=g) * 0.1, stride=s, relu=False).to(DEV)
+    pk = nn_ops.pack_dual(pc3, pd)
+    xa = torch.randn((N, Ho, Wo, Ca), generator=g).to(torch.bfloat16).to(DEV)
+    xb = torch.randn((N, Hb, Wb, Cb), generator=g).to(torch.bfloat16).to(DEV)
+    old = lib.md_conv2d_set_dual_pp_min_k(1 << 30)
+    try:
+        ref = nn_ops.conv1x1_dual(xa, xb, pk)
+        assert lib.md_conv2d_last_kernel() == 2
+    finally:
+        lib.md_conv2d_set_dual_pp_min_k(old)
+    got = nn_ops.conv1x1_dual(xa, xb, pk)
+    assert lib.md_conv2d_last_kernel() == 1, "the long-K dual GEMM did not reach the ping-pong kernel"
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
