@@ -95,6 +95,8 @@ def conv_out_hw(h, w, pc):
 
 
 import os as _os
+if _os.environ.get("MD_DUAL_PP_MIN_K"):   # A/B knob (tools): concatenated K from which md_conv1x1_dual runs on the ping-pong kernel
+    _lib.lib().md_conv2d_set_dual_pp_min_k(int(_os.environ["MD_DUAL_PP_MIN_K"]))
 if _os.environ.get("MD_PERS_MIN_K"):   # A/B knob (tools): K from which the persistent ping-pong form is the dispatcher's choice
     _lib.lib().md_conv2d_set_pers_min_k(int(_os.environ["MD_PERS_MIN_K"]))
 CONV_VARIANT = int(_os.environ.get("MD_CONV_VARIANT", "0"))  # 0 auto; other values force a kernel variant (A/B measurements, see md_conv2d_attrs; 31 = auto without conv1x1_stream_kernel)
