@@ -15,10 +15,14 @@
 // bf16x4 (ds_write_b64) into a [pixel][cout] LDS image and the tile leaves the CU as whole
 // 16-byte / 128-B-line NHWC stores, with bias, residual and ReLU fused.
 //
-// Three kernels (dispatcher + cost model at the end of the file):
+// Four kernels (dispatcher + cost model at the end of the file):
 //   conv_pingpong_kernel  256 x 256 x 64 tile, one 8-wave workgroup per CU, two staggered wave groups, LDS-DMA stream
 //                         with counted vmcnt -- the MFMA-bound layers (K >= 1024, Cout % 256 == 0), optionally with a
-//                         fused 1x1 head out of the epilogue image (md_conv2d_head);
+//                         fused 1x1 head out of the epilogue image (md_conv2d_head), in a PERSISTENT form for the long-K layers
+//                         without residual (next tile's prologue DMAs under a barrier-free slab epilogue), and with its K tiles
+//                         past the first tensor staged from a second, strided one (the long-K md_conv1x1_dual GEMMs);
+//   conv1x1_stream_kernel weight-stationary pointwise layers with K <= 512: weights in registers, activations through an LDS-DMA
+//                         ring, residual DMAed into the wave's epilogue image -- the HBM-bound expand / lateral convs;
 //   conv_igemm_kernel     128 x 128 x 64 (or 64- / 32-cout) tile, 4 waves, ONE LDS staging buffer -> four resident
 //                         workgroups per CU -- everything else;
 //   conv3x3_halo_kernel   3x3 / s1 layers with Cout <= 64: the 10 x 18 halo staged once per 64-channel chunk.
