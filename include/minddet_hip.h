@@ -30,7 +30,9 @@
  *     nparam, 2 = bad dtype/shape, 3 = HIP runtime error, 4 = unsupported size.  No
  *     exceptions, no stdout, no exit().
  *   - re-entrant, no global mutable state; safe to call from several host threads on
- *     different streams.
+ *     different streams.  (The only process-lifetime data are per-thread diagnostics counters --
+ *     md_conv2d_last_kernel / md_conv2d_launch_count -- and a write-once "LDS size attribute set"
+ *     cache per kernel and device.  Every tuning knob is a PER-CALL attribute: md_conv_tune.)
  */
 #ifndef MINDDET_HIP_H_
 #define MINDDET_HIP_H_
@@ -127,6 +129,21 @@ int md_circle_nms(MD_AOT_ARGS);
 /* ------------------------------------------------------------------------------------------
  * Conv + folded BN + (residual) + ReLU, implicit GEMM on MFMA (bf16 in, fp32 accumulate)
  * ------------------------------------------------------------------------------------------ */
+/* Per-call tuning knobs of the conv family (A/B tools and the tests that drive the chunked / multi-round paths on small tensors).
+ * All zero = the library's defaults; nothing persists between calls and nothing is shared between threads. */
+typedef struct md_conv_tune {
+    int32_t chunk_limit;       /* activation bytes above which the op runs the batch as consecutive image chunks on the same stream
+                                  (the kernels' 32-bit LDS-DMA offsets); 0 = the default and maximum, 2 GiB - 64 KiB */
+    int32_t stream_rounds;     /* conv1x1_stream_kernel: workgroup rounds the pixel range is cut into; 0 = default 1 */
+    int32_t stream_wgs_per_cu; /* conv1x1_stream_kernel: workgroups per CU the grid is sized for; 0 = default 2 */
+    int32_t stream_cache_bits; /* conv1x1_stream_kernel cache policy: 0 = default (6); else 8 | bits (1 = activation DMA nt,
+                                  2 = residual DMA nt, 4 = stores nt) */
+    int32_t pers_min_k;        /* the persistent form of the ping-pong kernel is the dispatcher's choice for eligible layers with
+                                  K >= this; 0 = default 2304 */
+    int32_t dual_pp_min_k;     /* md_conv1x1_dual runs on the ping-pong kernel when its concatenated K is >= this (and Cout % 256 == 0,
+                                  no residual tensor); 0 = default 768 */
+} md_conv_tune;
+
 typedef struct md_conv2d_attrs {
     int32_t kh, kw, stride, pad; /* square stride / symmetric zero padding */
     int32_t relu;                /* activation: 0 none; 1 ReLU applied after bias (+ residual);
@@ -157,7 +174,8 @@ typedef struct md_conv2d_attrs {
                                     the packed weights are for Cin = x_cin) */
     int32_t res_slice, res_c_off;/* res_slice != 0: residual is [N,Ho,Wo,R] and channels [res_c_off, res_c_off + Cout) are added
                                     (res_c_off % 8 == 0; unit output stride, no res_upsample) */
-    int32_t reserved0;           /* must be 0 */
+    int32_t reserved0;           /* must be 0 (MD_ERR_ARG otherwise) */
+    md_conv_tune tune;           /* all zero = defaults */
 } md_conv2d_attrs;
 /* Replaces Conv2d -> BatchNorm2d(eval) -> [+ residual] -> ReLU of the reference graphs
  * (centernet/src/resnet.py:109-178,181-252; centerpoint/det3d_ms/models/necks/rpn.py:9-154).
@@ -182,6 +200,7 @@ int md_conv2d_cout_tile(int cout);
 typedef struct md_conv1x1_dual_attrs {
     int32_t stride_b;   /* spatial stride of x_b (the block's stride) */
     int32_t relu;       /* 0 none, 1 ReLU after the sum */
+    md_conv_tune tune;  /* all zero = defaults (chunk_limit, dual_pp_min_k are read) */
 } md_conv1x1_dual_attrs;
 int md_conv1x1_dual(MD_AOT_ARGS);
 
@@ -205,7 +224,7 @@ int md_conv2d_head(MD_AOT_ARGS);
  *        wd / bd given (Cin == 64, residual NULL): the block's 1x1 downsample conv bf16(wd . x + bd), computed in the same launch
  *          from the x tile in LDS (the first block of a stage, resnet.py _make_layer: no downsample launch, no 512 B / pixel tensor);
  *        residual given: that tensor;   neither (Cin == 256): x itself (identity block).
- * out: y[N,H,W,256] bf16.   extra: unused. */
+ * out: y[N,H,W,256] bf16.   extra: NULL or md_conv_tune (chunk_limit is read). */
 int md_bottleneck(MD_AOT_ARGS);
 
 /* Which kernel the dispatcher launched for the calling host thread's most recent md_conv2d (0 before any call, or when
@@ -226,22 +245,6 @@ int md_conv2d_last_kernel(void);
  * md_bottleneck) have launched: a call on a batch past the chunk limit launches once per image chunk.  Diagnostic only:
  * bench.py divides a call's algorithmic work and bracketed time by its launches. */
 long long md_conv2d_launch_count(void);
-/* md_conv2d runs a batch whose activation tensor exceeds `bytes` (default and maximum: 2 GiB - 64 KiB, the reach of the
- * kernels' 32-bit LDS-DMA offsets) as consecutive image chunks on the same stream.  Returns the previous limit; tests
- * lower it to exercise the chunked path on small tensors. */
-long long md_conv2d_set_chunk_limit(long long bytes);
-/* Tools only: the number of workgroup rounds conv1x1_stream_kernel cuts a layer's pixel range into (default 1 = one resident
- * workgroup per slot streams its whole share).  Returns the previous value. */
-int md_conv2d_set_stream_rounds(int rounds);
-/* Tools only: workgroups per CU the grid of conv1x1_stream_kernel is sized for (default 2) and its cache-policy bits
- * (1 = activation DMA nt, 2 = residual DMA nt, 4 = stores nt; default 6). */
-int md_conv2d_set_stream_tune(int wgs_per_cu, int cache_bits);
-/* Tools only: the persistent form of the 256x256 ping-pong kernel is the dispatcher's choice for eligible layers with K >= k (default
- * 2304).  Returns the previous value. */
-int md_conv2d_set_pers_min_k(int k);
-/* Tools only: md_conv1x1_dual runs on the 256x256 ping-pong kernel when its concatenated K is >= k (default 768), Cout % 256 == 0 and
- * there is no residual tensor; otherwise on the 128x128 kernel.  Returns the previous value. */
-int md_conv2d_set_dual_pp_min_k(int k);
 
 /* ------------------------------------------------------------------------------------------
  * Streaming NHWC bf16 helpers between convs
@@ -268,6 +271,20 @@ int md_yolov8_decode(MD_AOT_ARGS);
  * unpinned).  in logits[R,S,S,Cpad] bf16, dets[R,6] f32 (x1,y1,x2,y2,score,label) ; out masks[R,S,S] f32 (zeros for empty
  * detection slots).  extra: int32 num_classes. */
 int md_mask_select(MD_AOT_ARGS);
+
+/* Mask R-CNN: paste each detection's S x S mask into the image (the standard last step of the mask branch, BASELINE configs[4]):
+ * bilinear resampling of the mask probabilities onto the pixel centres of the detection's box (grid_sample align_corners=False, zero
+ * padding: mmdet _do_paste_mask / torchvision paste_masks_in_image), then mask >= threshold.  Absent from the reference (README bullet):
+ * parity unpinned; oracle/np_ops.py::paste_masks restates the kernel's fp32 operation sequence, the comparison is bit-exact.
+ * in masks[R,S,S] f32, dets[R,6] f32 (x1,y1,x2,y2,score,label; slots with score 0 or an empty box give an all-zero mask) ;
+ * out bits != 0: words[R, img_h, ceil(img_w / 32)] i32 (bit j of word k of a row = pixel 32 k + j), else mask[R, img_h, img_w] u8 (0 / 1).
+ * One HBM-write-bound launch: img_h * img_w / 8 bytes per detection (bit form). */
+typedef struct md_paste_attrs {
+    int32_t img_h, img_w;
+    float threshold;   /* 0.5 in the public implementations */
+    int32_t bits;      /* 1: bit mask (32 pixels per int32 word), 0: uint8 mask */
+} md_paste_attrs;
+int md_paste_masks(MD_AOT_ARGS);
 
 /* Anchor target assignment on the device.  Replaces create_target_np
  * (minddet/models/pointpillars/src/core/target_assigner.py:29-166) as TargetAssigner.assign drives it (:196-224) with

@@ -1,6 +1,6 @@
 // aot.h -- host-side helpers shared by every entry point of libminddet_hip.so.
 // Argument checking for the MindSpore AOT-operator ABI (see include/minddet_hip.h) and
-// stream-ordered scratch.  No global mutable state.
+// stream-ordered scratch.  No global mutable state except the write-once LDS-attribute cache below.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -64,9 +64,36 @@ struct Scratch {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of once per launch: it is a driver call on the
+// launch path of every layer otherwise (r02 ADVICE; the YOLOv5s step is launch-bound) and would also run inside graph capture.
+// Write-once cache keyed by the kernel's host address (lock-free insert; a full table or a device id >= 8 just sets the attribute again).
+struct LdsAttrSlot { const void *k; int set[8]; };
+static LdsAttrSlot g_lds_attr[128];
+static inline int ensure_dyn_lds(const void *k, int lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MD_ERR_HIP;
+    const unsigned h0 = (unsigned)(((uintptr_t)k >> 3) * 2654435761u >> 16);
+    for (unsigned p = 0; p < 128 && dev >= 0 && dev < 8; ++p) {
+        LdsAttrSlot &sl = g_lds_attr[(h0 + p) & 127];
+        const void *cur = __atomic_load_n(&sl.k, __ATOMIC_ACQUIRE);
+        if (cur == nullptr) {
+            const void *expected = nullptr;
+            cur = __atomic_compare_exchange_n(&sl.k, &expected, k, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE) ? k : expected;
+        }
+        if (cur != k) continue;
+        if (__atomic_load_n(&sl.set[dev], __ATOMIC_ACQUIRE) >= lds) return MD_OK;
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+        __atomic_store_n(&sl.set[dev], lds, __ATOMIC_RELEASE);
+        return MD_OK;
+    }
+    return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess ? MD_OK : MD_ERR_HIP;
+}
+
 // records which conv-family kernel the calling host thread launched last (md_conv2d_last_kernel); defined in conv.hip
 void md_note_conv_kernel(int id);
-// activation bytes above which a conv-family op slices the batch (md_conv2d_set_chunk_limit; 2 GiB - 64 KiB unless a test lowered it)
-long long md_chunk_limit();
+// activation bytes above which a conv-family op slices the batch: md_conv_tune.chunk_limit of the call (tests lower it), default 2 GiB - 64 KiB
+static inline long long md_chunk_limit(const md_conv_tune *t) {
+    return t && t->chunk_limit > 0 && t->chunk_limit < 0x7fff0000 ? (long long)t->chunk_limit : 0x7fff0000LL;
+}
 
 }  // namespace md

@@ -471,12 +471,13 @@ extern "C" int md_bottleneck(MD_AOT_ARGS) {
     const long long x_img = H * W * Cin * 2;
     if (x_img >= 0x7fff0000LL) return MD_ERR_SIZE;
     // 32-bit DMA offsets: run the batch as image chunks whose x tensor stays below 2 GiB (as md_conv2d does; same limit, which
-    // tests lower through md_conv2d_set_chunk_limit)
-    const long long lim = md_chunk_limit() > x_img ? md_chunk_limit() : x_img;
+    // tests lower through md_conv_tune.chunk_limit of the call)
+    const long long chunk_lim = md_chunk_limit((const md_conv_tune *)extra);
+    const long long lim = chunk_lim > x_img ? chunk_lim : x_img;
     const long long per = lim / x_img < N ? lim / x_img : N;
     const int tiles_x = (int)((W + BN_TW - 1) / BN_TW), tiles_y = (int)((H + BN_TH - 1) / BN_TH);
     auto k = params[7] ? bottleneck64_kernel<2> : (params[6] ? bottleneck64_kernel<1> : bottleneck64_kernel<0>);
-    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, BN_LDS) != hipSuccess) return MD_ERR_HIP;
+    if (ensure_dyn_lds((const void *)k, BN_LDS) != MD_OK) return MD_ERR_HIP;
     for (long long n0 = 0; n0 < N; n0 += per) {
         const long long nn = N - n0 < per ? N - n0 : per;
         BottleneckArgs a;

@@ -90,7 +90,7 @@ struct ConvArgs {
     const uint16_t *x2;
     unsigned x2_bytes;
     int H2, W2, Xs2, stride2, nk_a;
-    int tune;               // conv1x1_stream_kernel cache-policy bits (tools: md_conv2d_set_stream_tune): 1 = x DMA nt, 2 = residual DMA nt, 4 = stores nt
+    int tune;               // conv1x1_stream_kernel cache-policy bits (md_conv_tune.stream_cache_bits): 1 = x DMA nt, 2 = residual DMA nt, 4 = stores nt
     int Rs;                 // 0: the residual has the output's layout; > 0: residual pixel m, channel c at m*Rs + c (a channel
                             // slice of a wider [N,Ho,Wo,Rs] tensor, a.res pointing at its first channel)
 };
@@ -133,8 +133,23 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((c
 static thread_local int g_last_kernel = 0;
 // kernels launched so far by this host thread's conv-family calls (md_conv2d_launch_count): a call on a batch past the chunk limit launches once per image chunk
 static thread_local long long g_launch_count = 0;
-// activation bytes above which md_conv2d slices the batch (the kernels' 32-bit DMA offsets); lowered only by tests
-static long long g_chunk_limit = 0x7fff0000LL;
+// Per-call tuning (md_conv_tune of the op's attribute struct, resolved against the defaults): the library keeps no mutable knob.
+struct Tune {
+    long long chunk_limit;   // activation bytes above which the batch is sliced into image chunks (the kernels' 32-bit DMA offsets)
+    int stream_rounds, stream_wgs_per_cu, stream_cache_bits, pers_min_k, dual_pp_min_k;
+};
+static Tune resolve_tune(const md_conv_tune *t) {
+    Tune r = {0x7fff0000LL, 1, 2, 6, 2304, 768};
+    if (!t) return r;
+    if (t->chunk_limit > 0 && t->chunk_limit < 0x7fff0000) r.chunk_limit = t->chunk_limit;
+    if (t->stream_rounds >= 1 && t->stream_rounds <= 64) r.stream_rounds = t->stream_rounds;
+    if (t->stream_wgs_per_cu >= 1 && t->stream_wgs_per_cu <= 8) r.stream_wgs_per_cu = t->stream_wgs_per_cu;
+    if (t->stream_cache_bits & 8) r.stream_cache_bits = t->stream_cache_bits & 7;
+    if (t->pers_min_k >= 1) r.pers_min_k = t->pers_min_k;
+    if (t->dual_pp_min_k >= 128) r.dual_pp_min_k = t->dual_pp_min_k;
+    return r;
+}
+
 
 // 16 zero bytes: the source of every out-of-image / past-K chunk when staging with LDS-DMA
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
@@ -534,23 +549,19 @@ static int launch_conv(ConvArgs &a, hipStream_t s) {
     constexpr bool HAS_PLAIN = MODE == 2;
     auto k = conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, 1>;
     if (plain) k = a.relu == 2 ? conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, HAS_PLAIN ? 2 : 1> : conv_igemm_kernel<NT, WC, WP, FC, FP, MODE, HAS_PLAIN ? 0 : 1>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return MD_ERR_HIP;
-    }
+    if (lds > 64 * 1024 && ensure_dyn_lds((const void *)k, lds) != MD_OK) return MD_ERR_HIP;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NT), lds, s, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
 
 static int launch_conv_dual_pingpong(ConvArgs &a, hipStream_t s);   // defined behind the ping-pong kernel
-static int g_dual_pp_min_k = 768;   // md_conv1x1_dual runs on the ping-pong kernel from this K on (tools: md_conv2d_set_dual_pp_min_k)
 
 // 128 x 128 single-buffer kernel on the K-concatenation of two inputs (md_conv1x1_dual)
-static int launch_conv_dual(ConvArgs &a, hipStream_t s) {
+static int launch_conv_dual(ConvArgs &a, hipStream_t s, const Tune &tn) {
     // long-K, MFMA-bound forms (768 -> 1024, 1536 -> 2048 of the ResNet-50 stages 3 / 4): the 256x256 ping-pong kernel reading its K tiles
     // past nk_a from the second tensor
-    if (a.Cout % 256 == 0 && a.Kpad >= g_dual_pp_min_k && !a.res && (long long)(a.M + 255) / 256 * (a.Cout / 256) >= 256)
+    if (a.Cout % 256 == 0 && a.Kpad >= tn.dual_pp_min_k && !a.res && (long long)(a.M + 255) / 256 * (a.Cout / 256) >= 256)
         return launch_conv_dual_pingpong(a, s);
     constexpr int CT = 128, PT = 128;
     ++g_launch_count;
@@ -811,18 +822,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
 
 // dispatch + launch of conv1x1_stream_kernel; MD_ERR_UNSUPPORTED_STREAM when the layer is not one it takes
 #define MD_ERR_UNSUPPORTED_STREAM 101
-static int g_stream_rounds = 1;   // workgroup rounds the pixel range is cut into (tools only: md_conv2d_set_stream_rounds)
-static int g_stream_wgs_per_cu = 2, g_stream_tune = 6;   // tools only: md_conv2d_set_stream_tune
-static int g_pers_min_k = 2304;   // the persistent form of the ping-pong kernel is the auto choice from this K on (tools: md_conv2d_set_pers_min_k)
 template <int K, int CB>
-static int launch_conv1x1_stream_t(ConvArgs &a, hipStream_t s) {
+static int launch_conv1x1_stream_t(ConvArgs &a, hipStream_t s, const Tune &tn) {
     constexpr int NR = K == 512 ? 2 : (K == 128 ? 4 : 3);
     constexpr int CT = 4 * CB * 32;
     const int lds = NR * 32 * K * 2 + 4 * (32 * CB * 64) + CT * 4;
     a.n_ctiles = a.Cout / CT;
     a.n_ptiles = (a.M + 31) / 32;
-    const long long slots = 256LL * g_stream_wgs_per_cu * g_stream_rounds;        // resident workgroups (two per CU)
-    a.tune = g_stream_tune;
+    const long long slots = 256LL * tn.stream_wgs_per_cu * tn.stream_rounds;      // resident workgroups (two per CU) x rounds
+    a.tune = tn.stream_cache_bits;
     long long tpw = ((long long)a.n_ptiles * a.n_ctiles + slots - 1) / slots;
     if (tpw < 4) tpw = 4;
     const long long n_chunks = (a.n_ptiles + tpw - 1) / tpw;
@@ -832,7 +840,7 @@ static int launch_conv1x1_stream_t(ConvArgs &a, hipStream_t s) {
     auto k = a.res ? (a.relu == 2 ? conv1x1_stream_kernel<K, CB, true, 1> : conv1x1_stream_kernel<K, CB, false, 1>)
                    : (a.relu == 2 ? conv1x1_stream_kernel<K, CB, true, 0> : conv1x1_stream_kernel<K, CB, false, 0>);
     if (a.res_up) k = conv1x1_stream_kernel<K, CB, false, 2>;
-    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+    if (ensure_dyn_lds((const void *)k, lds) != MD_OK) return MD_ERR_HIP;
     ++g_launch_count;
     g_last_kernel = MD_CONV_KERNEL_STREAM_1X1;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, a, (int)tpw, (int)n_chunks, (int)chunks_per_xcd);
@@ -848,12 +856,12 @@ static bool stream1x1_takes(const ConvArgs &a) {
     return a.Cout % 128 == 0;
 }
 
-static int launch_conv1x1_stream(ConvArgs &a, hipStream_t s) {
+static int launch_conv1x1_stream(ConvArgs &a, hipStream_t s, const Tune &tn) {
     if (!stream1x1_takes(a)) return MD_ERR_UNSUPPORTED_STREAM;
     const bool wide = a.Cout % 256 == 0;
-    if (a.Cin == 128) return wide ? launch_conv1x1_stream_t<128, 2>(a, s) : launch_conv1x1_stream_t<128, 1>(a, s);
-    if (a.Cin == 256) return wide ? launch_conv1x1_stream_t<256, 2>(a, s) : launch_conv1x1_stream_t<256, 1>(a, s);
-    return launch_conv1x1_stream_t<512, 1>(a, s);
+    if (a.Cin == 128) return wide ? launch_conv1x1_stream_t<128, 2>(a, s, tn) : launch_conv1x1_stream_t<128, 1>(a, s, tn);
+    if (a.Cin == 256) return wide ? launch_conv1x1_stream_t<256, 2>(a, s, tn) : launch_conv1x1_stream_t<256, 1>(a, s, tn);
+    return launch_conv1x1_stream_t<512, 1>(a, s, tn);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1070,7 +1078,7 @@ static int launch_conv3x3_halo(ConvArgs &a, hipStream_t s) {
     const int ep = HT_H * HT_W * (CT * 2 + 16) + CT * 4;  // epilogue image + bias copy
     const int lds = stage > ep ? stage : ep;
     auto k = conv3x3_halo_kernel<CT, ONE_HALO>;
-    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+    if (ensure_dyn_lds((const void *)k, lds) != MD_OK) return MD_ERR_HIP;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, a, tiles_x, tiles_y);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
@@ -1589,7 +1597,7 @@ static bool pingpong_wants_16x16(const ConvArgs &a) { return a.kh == 3 && a.kw =
 template <int MF>
 static int launch_conv_pingpong_head_mf(ConvArgs &a, hipStream_t s, long long blocks, int lds) {
     auto k = conv_pingpong_kernel<0, MF, 0, true>;
-    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+    if (ensure_dyn_lds((const void *)k, lds) != MD_OK) return MD_ERR_HIP;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
@@ -1616,7 +1624,7 @@ static int launch_conv_pingpong_pers(ConvArgs &a, hipStream_t s) {
     a.pt_per_xcd = (a.n_ptiles + 7) / 8;
     const int lds = 8 * 128 * ROWB + 256 * 4 + 8 * 2560;   // staging buffers + bias + eight wave-private slabs
     auto k = a.relu == 2 ? conv_pingpong_kernel<0, MF, 2, false, true> : conv_pingpong_kernel<0, MF, 0, false, true>;
-    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+    if (ensure_dyn_lds((const void *)k, lds) != MD_OK) return MD_ERR_HIP;
     hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
@@ -1631,7 +1639,7 @@ static int launch_conv_dual_pingpong(ConvArgs &a, hipStream_t s) {
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
     const int lds = 256 * (256 * 2 + 16) + 256 * 4;
     auto k = conv_pingpong_kernel<0, 0, 0>;
-    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+    if (ensure_dyn_lds((const void *)k, lds) != MD_OK) return MD_ERR_HIP;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
@@ -1651,7 +1659,7 @@ static int launch_conv_pingpong(ConvArgs &a, hipStream_t s) {
     const bool plain = HAS_PLAIN && (!a.adv || cat_only) && !a.res_up;
     auto k = conv_pingpong_kernel<ABL, MF, 1>;
     if (plain) k = a.relu == 2 ? conv_pingpong_kernel<ABL, MF, HAS_PLAIN ? 2 : 1> : conv_pingpong_kernel<ABL, MF, HAS_PLAIN ? 0 : 1>;
-    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+    if (ensure_dyn_lds((const void *)k, lds) != MD_OK) return MD_ERR_HIP;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
@@ -1666,36 +1674,6 @@ extern "C" int md_conv2d_last_kernel(void) { return g_last_kernel; }
 extern "C" long long md_conv2d_launch_count(void) { return g_launch_count; }
 namespace md {
 void md_note_conv_kernel(int id) { g_last_kernel = id; ++g_launch_count; }
-long long md_chunk_limit() { return g_chunk_limit; }
-}
-extern "C" long long md_conv2d_set_chunk_limit(long long bytes) {
-    const long long old = g_chunk_limit;
-    g_chunk_limit = bytes > 0 && bytes < 0x7fff0000LL ? bytes : 0x7fff0000LL;
-    return old;
-}
-
-extern "C" int md_conv2d_set_stream_rounds(int rounds) {   // tools only: workgroup rounds of conv1x1_stream_kernel (default 1)
-    const int old = g_stream_rounds;
-    g_stream_rounds = rounds >= 1 && rounds <= 64 ? rounds : 1;
-    return old;
-}
-
-extern "C" int md_conv2d_set_dual_pp_min_k(int k) {   // tools only
-    const int old = g_dual_pp_min_k;
-    g_dual_pp_min_k = k >= 128 ? k : 768;
-    return old;
-}
-
-extern "C" int md_conv2d_set_pers_min_k(int k) {   // tools only
-    const int old = g_pers_min_k;
-    g_pers_min_k = k >= 1 ? k : 2304;
-    return old;
-}
-
-extern "C" int md_conv2d_set_stream_tune(int wgs_per_cu, int cache_bits) {   // tools only
-    g_stream_wgs_per_cu = wgs_per_cu >= 1 && wgs_per_cu <= 8 ? wgs_per_cu : 2;
-    g_stream_tune = cache_bits & 7;
-    return 0;
 }
 
 extern "C" int md_conv2d_cout_tile(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
@@ -1720,15 +1698,18 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
         return MD_ERR_ARG;
     if (!ndims || !shapes || ndims[0] != 4 || ndims[1] != 2 || ndims[4] != 4) return MD_ERR_ARG;
     const md_conv2d_attrs *at = (const md_conv2d_attrs *)extra;
+    if (at->reserved0 != 0) return MD_ERR_ARG;
+    const Tune tn = resolve_tune(&at->tune);
+    const long long chunk_limit = tn.chunk_limit;   // per call (md_conv_tune.chunk_limit)
     // The LDS-DMA kernels address the activation tensor with 32-bit byte offsets.  A batch whose input (or output /
     // residual, which the kernels address with 64-bit math but the same image split applies to) exceeds 2 GiB is run
     // as consecutive image chunks on the same stream: every tensor of the call is sliced along N.
     {
         const long long n_img = shapes[0][0];
         const long long x_img = shapes[0][1] * shapes[0][2] * shapes[0][3] * 2;
-        if (n_img > 1 && x_img > 0 && x_img < g_chunk_limit && n_img * x_img >= g_chunk_limit && shapes[4][0] == n_img &&
+        if (n_img > 1 && x_img > 0 && x_img < chunk_limit && n_img * x_img >= chunk_limit && shapes[4][0] == n_img &&
             (!params[3] || (ndims[3] == 4 && shapes[3][0] == n_img))) {
-            const long long per_max = g_chunk_limit / x_img;                 // images a chunk may hold (>= 1)
+            const long long per_max = chunk_limit / x_img;                 // images a chunk may hold (>= 1)
             const long long n_chunks = (n_img + per_max - 1) / per_max;
             const long long per = (n_img + n_chunks - 1) / n_chunks;          // even split: no tiny last chunk
             const long long y_img = shapes[4][1] * shapes[4][2] * shapes[4][3] * 2;
@@ -1850,7 +1831,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     const bool stream_auto = variant == 0 && !no_stream && !head && dma_ok && stream1x1_takes(a) && a.Cout % 256 == 0 && a.Cin != 128 &&
                              (M + 31) / 32 * (a.Cout / (a.Cin == 512 ? 128 : 256)) >= 4096;
     if ((variant == 30 || stream_auto) && !head) {
-        const int rc = dma_ok ? launch_conv1x1_stream(a, s) : MD_ERR_UNSUPPORTED_STREAM;
+        const int rc = dma_ok ? launch_conv1x1_stream(a, s, tn) : MD_ERR_UNSUPPORTED_STREAM;
         if (rc != MD_ERR_UNSUPPORTED_STREAM) return rc;
         variant = 0;
     }
@@ -1902,7 +1883,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     {
         const bool cat_only_p = !a.adv || (a.os == 1 && a.oy == 0 && a.ox == 0 && a.Ho == a.Hf && a.Wo == a.Wf);
         const bool pers_ok = fast && dma_ok && a.Cout % 256 == 0 && !a.res && !a.res_up && cat_only_p && 32 % (a.Cout / 256) == 0 && pp_blocks > 256;
-        const bool pers_auto = variant == 0 && !no_pers && pp_ok && pers_ok && a.Kpad >= g_pers_min_k;
+        const bool pers_auto = variant == 0 && !no_pers && pp_ok && pers_ok && a.Kpad >= tn.pers_min_k;
         if ((variant == 32 || pers_auto) && pers_ok) return pingpong_wants_16x16(a) ? launch_conv_pingpong_pers<1>(a, s) : launch_conv_pingpong_pers<0>(a, s);
         if (variant == 32) variant = 0;
     }
@@ -1973,6 +1954,7 @@ extern "C" int md_conv2d_head(MD_AOT_ARGS) {
     if (rc != MD_OK) return rc;
     md_conv2d_attrs a1 = {};
     a1.kh = a1.kw = 1; a1.stride = 1; a1.pad = 0; a1.relu = 0; a1.variant = at->variant < 15 ? at->variant : 0;
+    a1.tune = at->tune;
     int64_t sw2[2] = {shapes[3][0], 256}, sb2[1] = {shapes[3][0]};
     int nd1[5] = {4, 2, 1, 0, 4};
     int64_t *sh1[5] = {sy, sw2, sb2, snull, shapes[5]};
@@ -2011,7 +1993,8 @@ extern "C" int md_conv1x1_dual(MD_AOT_ARGS) {
     const long long xa_img = Ho * Wo * Ca * 2, xb_img = Hb * Wb * Cb * 2, w_bytes = cout_pad * (Ca + Cb) * 2;
     const long long big = xa_img > xb_img ? xa_img : xb_img;
     if (big >= 0x7fff0000LL || w_bytes >= 0x7fff0000LL) return MD_ERR_SIZE;
-    const long long lim = g_chunk_limit > big ? g_chunk_limit : big;
+    const Tune tn = resolve_tune(&at->tune);
+    const long long lim = tn.chunk_limit > big ? tn.chunk_limit : big;
     const long long per = lim / big < N ? lim / big : N;     // images per launch: both inputs stay inside the DMA reach
     for (long long n0 = 0; n0 < N; n0 += per) {
         const long long nn = N - n0 < per ? N - n0 : per;
@@ -2028,7 +2011,7 @@ extern "C" int md_conv1x1_dual(MD_AOT_ARGS) {
         a.x_bytes = (unsigned)(nn * xa_img); a.w_bytes = (unsigned)w_bytes; a.x2_bytes = (unsigned)(nn * xb_img);
         a.Hf = (int)Ho; a.Wf = (int)Wo; a.Ctot = (int)Cout; a.os = 1; a.pointwise = 1;
         a.H2 = (int)Hb; a.W2 = (int)Wb; a.Xs2 = (int)Cb; a.stride2 = at->stride_b; a.nk_a = (int)(Ca / 64);
-        const int rc = launch_conv_dual(a, (hipStream_t)stream);
+        const int rc = launch_conv_dual(a, (hipStream_t)stream, tn);
         if (rc != MD_OK) return rc;
     }
     return MD_OK;

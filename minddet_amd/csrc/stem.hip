@@ -227,8 +227,7 @@ extern "C" int md_stem_pool(MD_AOT_ARGS) {
     const long long n_tiles = (long long)a.N * a.tiles_x * a.tiles_y;
     if (n_tiles > 0x7fffffffLL) return MD_ERR_SIZE;
     a.n_tiles = (int)n_tiles;
-    if (hipFuncSetAttribute((const void *)stem_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS) != hipSuccess)
-        return MD_ERR_HIP;
+    if (ensure_dyn_lds((const void *)stem_pool_kernel, ST_LDS) != MD_OK) return MD_ERR_HIP;
     const int grid = a.n_tiles < 256 * 2 ? a.n_tiles : 256 * 2;  // persistent: two workgroups per CU
     hipLaunchKernelGGL(stem_pool_kernel, dim3((unsigned)grid), dim3(256), ST_LDS, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;

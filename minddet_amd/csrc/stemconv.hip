@@ -154,7 +154,7 @@ static int launch_stem_conv(StemConvArgs &a, hipStream_t s) {
     constexpr int PATCH_ALLOC = ((PR * SC_ROWB / 16 + 63) / 64) * 1024;
     const int lds = PATCH_ALLOC + SC_TH * SC_TW * (COUT * 2 + 16);
     auto k = stem_conv_kernel<KH, COUT>;
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
+    if (lds > 64 * 1024 && ensure_dyn_lds((const void *)k, lds) != MD_OK) return MD_ERR_HIP;
     const int grid = a.n_tiles < 256 * 3 ? a.n_tiles : 256 * 3;   // persistent: up to three workgroups per CU
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;

@@ -364,3 +364,101 @@ extern "C" int md_mask_select(MD_AOT_ARGS) {
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
+
+// ------------------------------------------------------------------------------------------------ Mask R-CNN mask pasting
+// The last step of the mask branch (BASELINE configs[4]): each detection's S x S mask probabilities are resampled bilinearly onto
+// the pixels of its box at IMAGE resolution and thresholded -- the public definition (mmdet _do_paste_mask / torchvision
+// paste_masks_in_image: grid_sample(align_corners=False, zero padding) at pixel centres, mask >= threshold).  Absent from the
+// reference (Mask R-CNN is a README bullet, /root/reference/README.md:5-14): parity unpinned; oracle/np_ops.py::paste_masks restates
+// the SAME fp32 operation sequence (no fused multiply-adds: __fmul_rn / __fadd_rn below), so the comparison is bit-exact.
+// HBM-bound write kernel: one lane = one 32-pixel word of the bit mask (64 lanes = 256 contiguous bytes) or 4 pixels of the uint8
+// mask; words outside the box's support are written as zeros without touching the mask.
+//   u  = ((px + 0.5) - x0) * (1 / (x1 - x0));  ix = u * S - 0.5;  xl = floor(ix), fx = ix - xl  (same for y)
+//   v  = ((m[yl][xl] * (1 - fx) + m[yl][xl+1] * fx) * (1 - fy)) + ((m[yl+1][xl] * (1 - fx) + m[yl+1][xl+1] * fx) * fy), taps outside = 0
+#pragma clang fp contract(off)   // from here to the end of the file: every product and sum below rounds on its own, as in the numpy oracle
+namespace md {
+struct PasteArgs {
+    const float *masks;   // [R,S,S]
+    const float *dets;    // [R,6]
+    void *out;            // BITS: uint32 [R,H,Ww]; else uint8 [R,H,W]
+    int R, S, H, W, Ww;   // Ww = words (BITS) or 4-pixel groups (uint8) per row
+    float thr;
+};
+
+template <bool BITS>
+__global__ __launch_bounds__(256) void paste_masks_kernel(PasteArgs a) {
+    constexpr int PX = BITS ? 32 : 4;
+    const size_t total = (size_t)a.R * a.H * a.Ww;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int wx = (int)(e % a.Ww);
+        const size_t t = e / a.Ww;
+        const int py = (int)(t % a.H), r = (int)(t / a.H);
+        const float *d = a.dets + (size_t)r * 6;
+        const float x0 = d[0], y0 = d[1], bw = __fsub_rn(d[2], d[0]), bh = __fsub_rn(d[3], d[1]);
+        unsigned word = 0u;
+        if (d[4] > 0.f && bw > 0.f && bh > 0.f) {
+            const float Sf = (float)a.S;
+            const float inv_w = __fdiv_rn(1.0f, bw), inv_h = __fdiv_rn(1.0f, bh);
+            const float iy = __fsub_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fadd_rn((float)py, 0.5f), y0), inv_h), Sf), 0.5f);
+            const int px0 = wx * PX;
+            const float ix_first = __fsub_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fadd_rn((float)px0, 0.5f), x0), inv_w), Sf), 0.5f);
+            const float ix_last = __fsub_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fadd_rn((float)(px0 + PX - 1), 0.5f), x0), inv_w), Sf), 0.5f);
+            if (iy > -1.0f && iy < Sf && ix_last > -1.0f && ix_first < Sf) {
+                const float yl_f = floorf(iy);
+                const int yl = (int)yl_f;
+                const float fy = __fsub_rn(iy, yl_f), gy = __fsub_rn(1.0f, fy);
+                const float *m0 = a.masks + (size_t)r * a.S * a.S + (size_t)(yl < 0 ? 0 : yl) * a.S;
+                const float *m1 = a.masks + (size_t)r * a.S * a.S + (size_t)(yl + 1 < a.S ? yl + 1 : a.S - 1) * a.S;
+                const bool ok0 = yl >= 0, ok1 = yl + 1 < a.S;
+#pragma unroll 4
+                for (int j = 0; j < PX; ++j) {
+                    const int px = px0 + j;
+                    const float ix = __fsub_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fadd_rn((float)px, 0.5f), x0), inv_w), Sf), 0.5f);
+                    if (!(ix > -1.0f && ix < Sf) || px >= a.W) continue;
+                    const float xl_f = floorf(ix);
+                    const int xl = (int)xl_f;
+                    const float fx = __fsub_rn(ix, xl_f), gx = __fsub_rn(1.0f, fx);
+                    const bool okl = xl >= 0, okr = xl + 1 < a.S;
+                    const int cl = okl ? xl : 0, cr = okr ? xl + 1 : a.S - 1;
+                    const float v00 = ok0 && okl ? m0[cl] : 0.f, v01 = ok0 && okr ? m0[cr] : 0.f;
+                    const float v10 = ok1 && okl ? m1[cl] : 0.f, v11 = ok1 && okr ? m1[cr] : 0.f;
+                    const float top = __fadd_rn(__fmul_rn(v00, gx), __fmul_rn(v01, fx));
+                    const float bot = __fadd_rn(__fmul_rn(v10, gx), __fmul_rn(v11, fx));
+                    const float v = __fadd_rn(__fmul_rn(top, gy), __fmul_rn(bot, fy));
+                    if (v >= a.thr) word |= BITS ? (1u << j) : (1u << (8 * j));
+                }
+            }
+        }
+        if (BITS) {
+            reinterpret_cast<unsigned *>(a.out)[e] = word;
+        } else {   // 4 pixels of the uint8 mask; the last group of a ragged row is stored byte by byte
+            unsigned char *o = reinterpret_cast<unsigned char *>(a.out) + ((size_t)r * a.H + py) * a.W + (size_t)wx * 4;
+            if (wx * 4 + 4 <= a.W && (a.W & 3) == 0) *reinterpret_cast<unsigned *>(o) = word;
+            else
+                for (int j = 0; j < 4 && wx * 4 + j < a.W; ++j) o[j] = (unsigned char)((word >> (8 * j)) & 1u);
+        }
+    }
+}
+}  // namespace md
+
+extern "C" int md_paste_masks(MD_AOT_ARGS) {
+    // in: masks[R,S,S] f32, dets[R,6] f32 ; out: bits != 0: words[R,H,ceil(W/32)] i32 (bit j of word k = pixel 32 k + j), else mask[R,H,W] u8
+    if (nparam != 3) return MD_ERR_NPARAM;
+    if (!params || !extra || !ndims || !shapes || ndims[0] != 3 || ndims[2] != 3) return MD_ERR_ARG;
+    const md_paste_attrs *at = (const md_paste_attrs *)extra;
+    if (!md::dtype_is(dtypes, 0, "float32") || !md::dtype_is(dtypes, 1, "float32") || !md::dtype_is(dtypes, 2, at->bits ? "int32" : "uint8"))
+        return MD_ERR_ARG;
+    const int64_t R = shapes[0][0], S = shapes[0][1], H = at->img_h, W = at->img_w;
+    if (shapes[0][2] != S || S < 1 || S > 1024 || H < 1 || W < 1 || H > 32768 || W > 32768 || md::numel(ndims, shapes, 1) != R * 6) return MD_ERR_ARG;
+    const int64_t Ww = at->bits ? (W + 31) / 32 : (W + 3) / 4;
+    if (shapes[2][0] != R || shapes[2][1] != H || shapes[2][2] != (at->bits ? Ww : W)) return MD_ERR_ARG;
+    if (R == 0) return MD_OK;
+    if (!params[0] || !params[1] || !params[2]) return MD_ERR_ARG;
+    if (R > 0x7fffffffLL / 6) return MD_ERR_SIZE;
+    md::PasteArgs a = {(const float *)params[0], (const float *)params[1], params[2], (int)R, (int)S, (int)H, (int)W, (int)Ww, at->threshold};
+    const size_t total = (size_t)R * H * Ww, nb = (total + 255) / 256;
+    const unsigned grid = (unsigned)(nb < 65535u * 64 ? nb : 65535u * 64);
+    if (at->bits) hipLaunchKernelGGL(md::paste_masks_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(md::paste_masks_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
+}

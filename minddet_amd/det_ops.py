@@ -821,6 +821,31 @@ def mask_select(logits, dets, num_classes):
     return out
 
 
+class _PasteAttrs(ctypes.Structure):
+    _fields_ = [("img_h", ctypes.c_int32), ("img_w", ctypes.c_int32), ("threshold", ctypes.c_float), ("bits", ctypes.c_int32)]
+
+
+def paste_masks(masks, dets, img_hw, threshold=0.5, bits=True):
+    """[B,D,S,S] f32 mask probabilities + [B,D,6] detections -> image-resolution masks (md_paste_masks): bits=True ->
+    [B,D,H,ceil(W/32)] int32 words (bit j of word k = pixel 32 k + j), else [B,D,H,W] uint8 (0 / 1)."""
+    B, D, S = masks.shape[0], masks.shape[1], masks.shape[2]
+    H, W = int(img_hw[0]), int(img_hw[1])
+    if bits:
+        out = torch.empty((B * D, H, (W + 31) // 32), dtype=torch.int32, device=masks.device)
+    else:
+        out = torch.empty((B * D, H, W), dtype=torch.uint8, device=masks.device)
+    _lib.call("md_paste_masks", [_f32c(masks).reshape(B * D, S, S), _f32c(dets).reshape(B * D, 6), out],
+              extra=_PasteAttrs(H, W, float(threshold), int(bool(bits))))
+    return out.view(B, D, H, out.shape[2])
+
+
+def unpack_mask_bits(words, width):
+    """[..., H, ceil(W/32)] int32 bit masks -> [..., H, W] uint8 (host-side helper for tests / result export)."""
+    w = words.to(torch.int64) & 0xffffffff
+    sh = torch.arange(32, device=words.device, dtype=torch.int64)
+    return ((w.unsqueeze(-1) >> sh) & 1).reshape(*words.shape[:-1], -1)[..., :width].to(torch.uint8)
+
+
 def dets_to_rois(dets):
     """[B,D,6] detections -> [B*D,5] RoIs (batch index, x1, y1, x2, y2) for the mask head (layout plumbing)."""
     B, D = dets.shape[0], dets.shape[1]

@@ -179,6 +179,12 @@ class ResNet:
     def to(self, device):
         for m in self.modules():
             m.to(device)
+        # the fused-block / dual-GEMM packs are derived from the conv packs just rebuilt (PackedDual and PackedBottleneck.b12 hold their own
+        # copies): drop them, or a forward pass after a weight change + .to() would keep running the old weights in those launches
+        for st in self.stages:
+            for b in st:
+                if isinstance(b, Bottleneck):
+                    b._fused = b._dual = False
         self.stem = None
         if self.conv1.cout == 64 and self.conv1.relu:  # the fused conv + BN + ReLU + maxpool kernel (md_stem_pool)
             self.stem = nn_ops.pack_stem(self.conv1.weight, bn=self.conv1.bn, bias=self.conv1.bias).to(device)
@@ -544,11 +550,16 @@ class FCNMaskHead:
 
 @DETECTORS.register_module
 class MaskRCNN(FasterRCNN):
-    """Faster R-CNN + FCNMaskHead on the final detections: forward -> (dets [B,max_det,6], count [B], masks [B,max_det,28,28])."""
+    """Faster R-CNN + FCNMaskHead on the final detections: forward -> (dets [B,max_det,6], count [B], masks [B,max_det,28,28]).
+    test_cfg.paste_masks (or forward(paste=True)): a fourth output, the masks pasted into the image at `mask_thr_binary` (md_paste_masks):
+    [B,max_det,H,ceil(W/32)] int32 bit masks (bit j of word k of a row = pixel 32 k + j)."""
 
     def __init__(self, backbone, neck, rpn_head, roi_head, mask_head, train_cfg=None, test_cfg=None):
         super().__init__(backbone, neck, rpn_head, roi_head, train_cfg, test_cfg)
         self.mask_head = build_roi_head(mask_head)
+        tc = test_cfg or {}
+        self.paste = bool(tc.get("paste_masks", False))
+        self.mask_thr = float(tc.get("mask_thr_binary", 0.5))
 
     def to(self, device):
         super().to(device)
@@ -558,13 +569,19 @@ class MaskRCNN(FasterRCNN):
     def conv_modules(self):
         return super().conv_modules() + self.mask_head.modules()
 
-    def forward(self, images, return_aux=False):
+    def forward(self, images, return_aux=False, paste=None):
         dets, count, aux = FasterRCNN.forward(self, images, return_aux=True)
         masks, aux_mask = self.mask_head(aux["feats"], dets)
+        out = (dets, count, masks)
+        if self.paste if paste is None else paste:
+            img_hw = (images.shape[1], images.shape[2])
+            if images.shape[3] == 4:  # stem layout: the border is not image
+                img_hw = (img_hw[0] - nn_ops.STEM_PAD_LO - nn_ops.STEM_PAD_HI, img_hw[1] - nn_ops.STEM_PAD_LO - nn_ops.STEM_PAD_HI)
+            out = out + (det_ops.paste_masks(masks, dets, img_hw, self.mask_thr, bits=True),)
         if return_aux:
             aux["mask"] = aux_mask
-            return dets, count, masks, aux
-        return dets, count, masks
+            return out + (aux,)
+        return out
 
     __call__ = forward
 
@@ -843,6 +860,8 @@ class YOLOv5:
     def to(self, device):
         for m in self.conv_modules():
             m.to(device)
+        for blk in (self.b2, self.b4, self.b6, self.b8, self.h13, self.h17, self.h20, self.h23):
+            blk._cv12 = None     # merged packs are derived copies: rebuilt from the (possibly re-loaded) weights on next use
         # the 3-channel stride-2 stem conv on the 4-channel stem layout (md_stem_conv) when the batch arrives in it
         self.stem = nn_ops.pack_stem_conv(self.b0.weight, bn=self.b0.bn, bias=self.b0.bias, act=self.b0.act)
         if self.stem is not None:
@@ -1005,6 +1024,9 @@ class YOLOv8:
     def to(self, device):
         for m in self.conv_modules():
             m.to(device)
+        for blk in (self.b2, self.b4, self.b6, self.b8, self.h12, self.h15, self.h18, self.h21):
+            blk._cv1 = None      # merged packs are derived copies: rebuilt from the (possibly re-loaded) weights on next use
+        self._stem2 = {}
         # the 3-channel stride-2 stem conv on the 4-channel stem layout (md_stem_conv) when the batch arrives in it
         self.stem = nn_ops.pack_stem_conv(self.b0.weight, bn=self.b0.bn, bias=self.b0.bias, act=self.b0.act)
         if self.stem is not None:

@@ -13,6 +13,12 @@ import torch
 from . import _lib
 
 
+class ConvTune(ctypes.Structure):
+    """md_conv_tune: per-call tuning knobs of the conv family (all zero = the library's defaults; nothing persists in the library)."""
+    _fields_ = [("chunk_limit", ctypes.c_int32), ("stream_rounds", ctypes.c_int32), ("stream_wgs_per_cu", ctypes.c_int32),
+                ("stream_cache_bits", ctypes.c_int32), ("pers_min_k", ctypes.c_int32), ("dual_pp_min_k", ctypes.c_int32)]
+
+
 class _ConvAttrs(ctypes.Structure):
     _fields_ = [("kh", ctypes.c_int32), ("kw", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32),
                 ("relu", ctypes.c_int32), ("variant", ctypes.c_int32), ("adv", ctypes.c_int32), ("pad_top", ctypes.c_int32),
@@ -20,7 +26,7 @@ class _ConvAttrs(ctypes.Structure):
                 ("out_stride", ctypes.c_int32), ("out_off_y", ctypes.c_int32), ("out_off_x", ctypes.c_int32),
                 ("c_off", ctypes.c_int32), ("cout", ctypes.c_int32), ("res_upsample", ctypes.c_int32), ("korder", ctypes.c_int32),
                 ("x_c_off", ctypes.c_int32), ("x_cin", ctypes.c_int32), ("res_slice", ctypes.c_int32), ("res_c_off", ctypes.c_int32),
-                ("reserved0", ctypes.c_int32)]
+                ("reserved0", ctypes.c_int32), ("tune", ConvTune)]
 
 
 def cout_tile(cout):
@@ -95,14 +101,13 @@ def conv_out_hw(h, w, pc):
 
 
 import os as _os
-if _os.environ.get("MD_DUAL_PP_MIN_K"):   # A/B knob (tools): concatenated K from which md_conv1x1_dual runs on the ping-pong kernel
-    _lib.lib().md_conv2d_set_dual_pp_min_k(int(_os.environ["MD_DUAL_PP_MIN_K"]))
-if _os.environ.get("MD_PERS_MIN_K"):   # A/B knob (tools): K from which the persistent ping-pong form is the dispatcher's choice
-    _lib.lib().md_conv2d_set_pers_min_k(int(_os.environ["MD_PERS_MIN_K"]))
+# A/B knobs (tools): MD_DUAL_PP_MIN_K = concatenated K from which md_conv1x1_dual runs on the ping-pong kernel, MD_PERS_MIN_K = K from
+# which the persistent ping-pong form is the dispatcher's choice.  They travel in every call's attribute struct (md_conv_tune).
+TUNE = ConvTune(dual_pp_min_k=int(_os.environ.get("MD_DUAL_PP_MIN_K", "0")), pers_min_k=int(_os.environ.get("MD_PERS_MIN_K", "0")))
 CONV_VARIANT = int(_os.environ.get("MD_CONV_VARIANT", "0"))  # 0 auto; other values force a kernel variant (A/B measurements, see md_conv2d_attrs; 31 = auto without conv1x1_stream_kernel)
 
 
-def conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0, res_upsample=False, x_c_off=None, res_c_off=None):
+def conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0, res_upsample=False, x_c_off=None, res_c_off=None, tune=None):
     """x [N,H,W,Cin] bf16 NHWC contiguous CUDA tensor -> y [N,Ho,Wo,Cout] bf16.
     With `out` wider than the layer (channel concat, rpn.py:152) the result goes to channels
     [c_off, c_off + Cout) of `out`.  x_c_off: the layer reads channels [x_c_off, x_c_off + pc.cin) of a wider x;
@@ -116,6 +121,7 @@ def conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0, res
     attrs = _ConvAttrs(pc.kh, pc.kw, pc.stride, pc.pad, int(pc.relu if relu is None else relu),
                        int(CONV_VARIANT if variant is None else variant))
     attrs.korder = getattr(pc, "korder", 0)
+    attrs.tune = TUNE if tune is None else tune
     attrs.res_upsample = int(bool(res_upsample))
     if x_c_off is not None:
         attrs.x_c_off, attrs.x_cin = int(x_c_off), pc.cin
@@ -128,7 +134,7 @@ def conv2d(x, pc, residual=None, relu=None, out=None, variant=None, c_off=0, res
     return out
 
 
-def conv2d_head(x, pc, pc2, variant=None):
+def conv2d_head(x, pc, pc2, variant=None, tune=None):
     """conv (256 output channels, ReLU) + 1x1 head with <= 16 output channels in one md_conv2d_head call: [N,H,W,Cin] ->
     [N,Ho,Wo,16] bf16 (the RPN head).  Falls back to two md_conv2d launches inside the library where the fused kernel
     does not apply."""
@@ -139,6 +145,7 @@ def conv2d_head(x, pc, pc2, variant=None):
     y2 = torch.empty((n, ho, wo, 16), dtype=torch.bfloat16, device=x.device)
     attrs = _ConvAttrs(pc.kh, pc.kw, pc.stride, pc.pad, 1, int(CONV_VARIANT if variant is None else variant))
     attrs.korder = getattr(pc, "korder", 0)
+    attrs.tune = TUNE if tune is None else tune
     _lib.call("md_conv2d_head", [x, pc.w, pc.bias, pc2.w, pc2.bias, y2], extra=attrs)
     return y2
 
@@ -180,7 +187,7 @@ def pack_bottleneck(pc1, pc2, pc3, pd=None):
     return PackedBottleneck(pc1, pc2, pc3, pd if fuse_ds else None)
 
 
-def bottleneck(x, blk, residual=None, out=None):
+def bottleneck(x, blk, residual=None, out=None, tune=None):
     """y = relu(conv3(relu(conv2(relu(conv1(x))))) + residual) in one md_bottleneck launch.  residual None: the block's own
     downsample conv if it was packed into blk (computed in the launch), else x itself (identity block)."""
     n, h, w, c = x.shape
@@ -190,12 +197,12 @@ def bottleneck(x, blk, residual=None, out=None):
         out = torch.empty((n, h, w, 256), dtype=torch.bfloat16, device=x.device)
     fused_ds = blk.wd is not None and residual is None
     _lib.call("md_bottleneck", [x, blk.w1, blk.b12, blk.w2, blk.w3, blk.b3, residual, blk.wd if fused_ds else None,
-                                blk.bd if fused_ds else None, out])
+                                blk.bd if fused_ds else None, out], extra=tune)
     return out
 
 
 class _DualAttrs(ctypes.Structure):
-    _fields_ = [("stride_b", ctypes.c_int32), ("relu", ctypes.c_int32)]
+    _fields_ = [("stride_b", ctypes.c_int32), ("relu", ctypes.c_int32), ("tune", ConvTune)]
 
 
 class PackedDual:
@@ -221,14 +228,14 @@ def pack_dual(pc3, pd):
     return PackedDual(pc3, pd) if ok else None
 
 
-def conv1x1_dual(xa, xb, pk, out=None):
+def conv1x1_dual(xa, xb, pk, out=None, tune=None):
     """y = act(w3 . xa + wd . xb[:, ::s, ::s] + b3 + bd) in one launch (xa [N,Ho,Wo,Ca], xb [N,Hb,Wb,Cb])."""
     n, ho, wo, ca = xa.shape
     if ca != pk.ca or xb.shape[3] != pk.cb:
         raise _lib.MindDetHipError(f"conv1x1_dual: inputs have {ca} / {xb.shape[3]} channels, packed for {pk.ca} / {pk.cb}")
     if out is None:
         out = torch.empty((n, ho, wo, pk.cout), dtype=torch.bfloat16, device=xa.device)
-    _lib.call("md_conv1x1_dual", [xa, xb, pk.w, pk.bias, None, out], extra=_DualAttrs(int(pk.stride), int(pk.relu)))
+    _lib.call("md_conv1x1_dual", [xa, xb, pk.w, pk.bias, None, out], extra=_DualAttrs(int(pk.stride), int(pk.relu), TUNE if tune is None else tune))
     return out
 
 
@@ -279,6 +286,7 @@ def conv_transpose2d(x, pct, out=None, c_off=0):
         attrs.adv, attrs.pad_top, attrs.pad_left, attrs.sub_h, attrs.sub_w = 1, m["pad_top"], m["pad_left"], h, w
         attrs.out_stride, attrs.out_off_y, attrs.out_off_x, attrs.c_off, attrs.cout = s, m["py"], m["px"], int(c_off), pc.cout
         attrs.korder = getattr(pc, "korder", 0)
+        attrs.tune = TUNE
         _lib.call("md_conv2d", [x, pc.w, pc.bias, None, out], extra=attrs)
     return out
 

@@ -650,3 +650,41 @@ def create_target(anchors, gt_boxes, gt_classes, matched_thr, unmatched_thr, anc
     labels[inside] = lab
     weights[inside] = (lab > 0).astype(np.float32)
     return labels, targets, weights, gt_ids
+
+
+def paste_masks(masks, dets, img_hw, threshold=0.5):
+    """Mask R-CNN mask pasting (public definition: mmdet _do_paste_mask / torchvision paste_masks_in_image -- grid_sample with
+    align_corners=False and zero padding at pixel centres, then mask >= threshold; absent from the reference, whose Mask R-CNN is a README
+    bullet: parity unpinned).  Same float32 operation sequence as md_paste_masks (csrc/twostage.hip), every product / sum rounded on its
+    own.  masks [R,S,S] f32, dets [R,6] f32 -> [R,H,W] uint8."""
+    f32 = np.float32
+    masks = np.asarray(masks, f32)
+    dets = np.asarray(dets, f32)
+    R, S = masks.shape[0], masks.shape[1]
+    H, W = img_hw
+    out = np.zeros((R, H, W), np.uint8)
+    px = np.arange(W, dtype=f32) + f32(0.5)
+    py = np.arange(H, dtype=f32) + f32(0.5)
+    Sf = f32(S)
+    for r in range(R):
+        x0, y0 = dets[r, 0], dets[r, 1]
+        bw, bh = f32(dets[r, 2] - dets[r, 0]), f32(dets[r, 3] - dets[r, 1])
+        if not (dets[r, 4] > 0 and bw > 0 and bh > 0):
+            continue
+        inv_w, inv_h = f32(1.0) / bw, f32(1.0) / bh
+        ix = (((px - x0) * inv_w) * Sf - f32(0.5)).astype(f32)
+        iy = (((py - y0) * inv_h) * Sf - f32(0.5)).astype(f32)
+        okx, oky = (ix > -1) & (ix < Sf), (iy > -1) & (iy < Sf)
+        xl_f, yl_f = np.floor(ix), np.floor(iy)
+        fx, fy = (ix - xl_f).astype(f32), (iy - yl_f).astype(f32)
+        gx, gy = (f32(1.0) - fx).astype(f32), (f32(1.0) - fy).astype(f32)
+        xl, yl = xl_f.astype(np.int64), yl_f.astype(np.int64)
+        mp = np.zeros((S + 2, S + 2), f32)      # zero border = the out-of-range taps
+        mp[1:-1, 1:-1] = masks[r]
+        xi = np.clip(xl + 1, 0, S)              # index of the LEFT tap in the padded mask (clipped where the pixel is outside anyway)
+        yi = np.clip(yl + 1, 0, S)
+        top = (mp[yi][:, xi] * gx[None, :]).astype(f32) + (mp[yi][:, xi + 1] * fx[None, :]).astype(f32)
+        bot = (mp[yi + 1][:, xi] * gx[None, :]).astype(f32) + (mp[yi + 1][:, xi + 1] * fx[None, :]).astype(f32)
+        v = (top.astype(f32) * gy[:, None]).astype(f32) + (bot.astype(f32) * fy[:, None]).astype(f32)
+        out[r] = ((v.astype(f32) >= f32(threshold)) & oky[:, None] & okx[None, :]).astype(np.uint8)
+    return out

@@ -37,6 +37,39 @@ def test_wrong_nparam_is_an_error_code_not_a_crash():
         assert rc == 1  # iou-bev-nms-org.cpp:238 convention
 
 
+def test_no_process_wide_tuning_setters_and_reserved0_is_checked():
+    """include/minddet_hip.h promises 're-entrant, no global mutable state': the conv family's tuning knobs are per-call attributes
+    (md_conv_tune), the library exports no setter, and md_conv2d_attrs.reserved0 != 0 is MD_ERR_ARG (checked before any device call,
+    so this runs without a GPU)."""
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    hdr = open(os.path.join(ROOT, "include", "minddet_hip.h")).read()
+    assert "md_conv2d_set_" not in hdr
+    for n in ("md_conv2d_set_chunk_limit", "md_conv2d_set_stream_rounds", "md_conv2d_set_stream_tune", "md_conv2d_set_pers_min_k",
+              "md_conv2d_set_dual_pp_min_k"):
+        assert not hasattr(lib, n), f"{n}: a process-wide knob is back in the product library"
+    from minddet_amd import nn_ops
+
+    # the ctypes mirror has the header's field list (23 int32 + 6 int32 of md_conv_tune)
+    m = re.search(r"typedef struct md_conv2d_attrs \{(.*?)\} md_conv2d_attrs;", hdr, flags=re.S)
+    body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+    n_i32 = sum(len(d.split(",")) for d in re.findall(r"int32_t\s+([^;]+);", body))
+    assert n_i32 == 23 and "md_conv_tune tune;" in body
+    assert ctypes.sizeof(nn_ops._ConvAttrs) == 4 * (23 + 6) and ctypes.sizeof(nn_ops.ConvTune) == 24
+    assert ctypes.sizeof(nn_ops._DualAttrs) == 4 * (2 + 6)
+    # reserved0 != 0 -> rc 2; dummy host pointers are never dereferenced on this path
+    n = 5
+    dummy = (ctypes.c_char * 64)()
+    params = (ctypes.c_void_p * n)(*[ctypes.addressof(dummy)] * n)
+    ndims = (ctypes.c_int * n)(4, 2, 1, 4, 4)
+    sh = [(ctypes.c_int64 * 4)(1, 8, 8, 64), (ctypes.c_int64 * 2)(64, 64), (ctypes.c_int64 * 1)(64), (ctypes.c_int64 * 4)(1, 8, 8, 64),
+          (ctypes.c_int64 * 4)(1, 8, 8, 64)]
+    shapes = (ctypes.POINTER(ctypes.c_int64) * n)(*[ctypes.cast(b, ctypes.POINTER(ctypes.c_int64)) for b in sh])
+    dtypes = (ctypes.c_char_p * n)(b"bfloat16", b"bfloat16", b"float32", b"bfloat16", b"bfloat16")
+    attrs = nn_ops._ConvAttrs(1, 1, 1, 0, 0, 0)
+    attrs.reserved0 = 1
+    assert lib.md_conv2d(n, params, ndims, shapes, dtypes, None, ctypes.byref(attrs)) == 2
+
+
 def test_product_never_imports_oracle():
     pat = re.compile(r"^\s*(from|import)\s+oracle\b|oracle[./]_ref|liboracle", re.M)
     for d, _, files in os.walk(os.path.join(ROOT, "minddet_amd")):

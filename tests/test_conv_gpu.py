@@ -190,13 +190,11 @@ def test_conv_batch_chunking_is_bit_identical():
     x = torch.randn((5, 20, 24, 64), generator=g).to(torch.bfloat16).to(DEV)
     r = torch.randn((5, 20, 24, 128), generator=g).to(torch.bfloat16).to(DEV)
     y0 = nn_ops.conv2d(x, pc, residual=r)
-    fn = _lib.lib().md_conv2d_set_chunk_limit
-    fn.restype, fn.argtypes = ctypes.c_longlong, [ctypes.c_longlong]
-    old = fn(2 * 20 * 24 * 64 * 2 + 1)  # two images per chunk -> 3 launches
-    try:
-        y1 = nn_ops.conv2d(x, pc, residual=r)
-    finally:
-        fn(old)
+    lc = _lib.lib().md_conv2d_launch_count
+    lc.restype = ctypes.c_longlong
+    l0 = lc()
+    y1 = nn_ops.conv2d(x, pc, residual=r, tune=nn_ops.ConvTune(chunk_limit=2 * 20 * 24 * 64 * 2 + 1))  # two images per chunk -> 3 launches
+    assert lc() - l0 == 3
     torch.cuda.synchronize()
     assert torch.equal(y0, y1)
 
@@ -239,13 +237,8 @@ def test_conv2d_head_batch_chunking_is_bit_identical():
     pc2 = nn_ops.pack_conv(torch.randn((15, 256, 1, 1), generator=g) * 0.05, bias=torch.randn((15,), generator=g) * 0.1).to(DEV)
     x = torch.randn((3, 96, 96, 256), generator=g).to(torch.bfloat16).to(DEV)
     y0 = nn_ops.conv2d_head(x, pc, pc2)
-    fn = _lib.lib().md_conv2d_set_chunk_limit
-    fn.restype, fn.argtypes = ctypes.c_longlong, [ctypes.c_longlong]
-    old = fn(2 * 96 * 96 * 256 * 2 + 1)   # two images per chunk: the second chunk (one image, 36 tiles) takes the two-launch path
-    try:
-        y1 = nn_ops.conv2d_head(x, pc, pc2)
-    finally:
-        fn(old)
+    # two images per chunk: the second chunk (one image, 36 tiles) takes the two-launch path
+    y1 = nn_ops.conv2d_head(x, pc, pc2, tune=nn_ops.ConvTune(chunk_limit=2 * 96 * 96 * 256 * 2 + 1))
     torch.cuda.synchronize()
     assert torch.equal(y0[:2], y1[:2])
     assert (y0[2].float() - y1[2].float()).abs().max().item() <= 2e-2 * (1 + y0[2].float().abs().max().item())
@@ -414,13 +407,7 @@ def test_fused_bottleneck_argument_checks_and_determinism():
     # batches whose x tensor exceeds the DMA reach run as image chunks: same result through a lowered limit (5 images -> 2 + 2 + 1)
     x5 = torch.randn((5, 16, 32, 256), generator=g).to(torch.bfloat16).to(DEV)
     y5 = nn_ops.bottleneck(x5, blk)
-    lib = _lib.lib()
-    lib.md_conv2d_set_chunk_limit.restype = ctypes.c_longlong
-    old_lim = lib.md_conv2d_set_chunk_limit(ctypes.c_longlong(2 * 16 * 32 * 256 * 2 + 1))
-    try:
-        y5c = nn_ops.bottleneck(x5, blk)
-    finally:
-        lib.md_conv2d_set_chunk_limit(ctypes.c_longlong(old_lim))
+    y5c = nn_ops.bottleneck(x5, blk, tune=nn_ops.ConvTune(chunk_limit=2 * 16 * 32 * 256 * 2 + 1))
     assert torch.equal(y5, y5c)
     # blocks md_bottleneck does not take are not packed: the graph keeps the three-launch path for them
     p128 = nn_ops.pack_conv(torch.randn((128, 512, 1, 1)) * 0.05, relu=True).to(DEV)
@@ -591,11 +578,7 @@ def test_conv1x1_stream_kernel_many_tiles_per_workgroup_and_rounds():
         r = torch.randn((6, 100, 167, Cout), generator=g).to(torch.bfloat16).to(DEV)
         ref = nn_ops.conv2d(x, pc, residual=r, variant=20)
         for rounds in (1, 3):
-            old = lib.md_conv2d_set_stream_rounds(rounds)
-            try:
-                got = nn_ops.conv2d(x, pc, residual=r, variant=30)
-            finally:
-                lib.md_conv2d_set_stream_rounds(old)
+            got = nn_ops.conv2d(x, pc, residual=r, variant=30, tune=nn_ops.ConvTune(stream_rounds=rounds))
             assert lib.md_conv2d_last_kernel() == 8
             assert torch.equal(got, ref), (Cin, Cout, rounds)
     # not pointwise / K = 64 / Cout not a multiple of 128: variant 30 is the dispatcher's own choice
@@ -631,11 +614,7 @@ def test_conv1x1_stream_kernel_random_shapes_against_the_tile_kernel():
         elif kind == 2:
             r = torch.randn((n, (h + 1) // 2, (w + 1) // 2, cout), generator=g).to(torch.bfloat16).to(DEV)
         ref = nn_ops.conv2d(x, pc, residual=r, res_upsample=kind == 2, variant=20)
-        old = lib.md_conv2d_set_stream_rounds(rounds)
-        try:
-            got = nn_ops.conv2d(x, pc, residual=r, res_upsample=kind == 2, variant=30)
-        finally:
-            lib.md_conv2d_set_stream_rounds(old)
+        got = nn_ops.conv2d(x, pc, residual=r, res_upsample=kind == 2, variant=30, tune=nn_ops.ConvTune(stream_rounds=rounds))
         assert lib.md_conv2d_last_kernel() == 8, (case, cin, cout)
         assert torch.equal(got, ref), (case, cin, cout, n, h, w, kind, act, rounds)
 
@@ -697,12 +676,8 @@ def test_conv1x1_dual_on_the_pingpong_kernel(cfg):
     pk = nn_ops.pack_dual(pc3, pd)
     xa = torch.randn((N, Ho, Wo, Ca), generator=g).to(torch.bfloat16).to(DEV)
     xb = torch.randn((N, Hb, Wb, Cb), generator=g).to(torch.bfloat16).to(DEV)
-    old = lib.md_conv2d_set_dual_pp_min_k(1 << 30)
-    try:
-        ref = nn_ops.conv1x1_dual(xa, xb, pk)
-        assert lib.md_conv2d_last_kernel() == 2
-    finally:
-        lib.md_conv2d_set_dual_pp_min_k(old)
+    ref = nn_ops.conv1x1_dual(xa, xb, pk, tune=nn_ops.ConvTune(dual_pp_min_k=1 << 30))
+    assert lib.md_conv2d_last_kernel() == 2
     got = nn_ops.conv1x1_dual(xa, xb, pk)
     assert lib.md_conv2d_last_kernel() == 1, "the long-K dual GEMM did not reach the ping-pong kernel"
     torch.cuda.synchronize()

@@ -165,7 +165,12 @@ def test_full_size_structural_properties():
     # the same batch in the stem layout (fused stem kernel): same shapes, (nearly) the same detections
     from minddet_amd import nn_ops
     dets4, count4 = m.forward(nn_ops.to_stem_layout(x))
-    assert dets4.shape == dets.shape and (count4.cpu() - count.cpu()).abs().max().item() <= 5
+    # (md_stem_pool accumulates the 7x7 window in another K order than md_conv2d + md_maxpool2d: last-bit differences in the stem's bf16
+    # output; measured on this batch (r03): identical counts, top scores within 1e-3)
+    cdiff = (count4.cpu() - count.cpu()).abs().max().item()
+    sdiff = (dets4[:, 0, 4] - dets[:, 0, 4]).abs().max().item()
+    print("stem-layout vs 8-channel path: max count difference", cdiff, "max top-score difference", sdiff)
+    assert dets4.shape == dets.shape and cdiff <= 2 and sdiff <= 1e-2
     d, c = dets.cpu().numpy(), count.cpu().numpy()
     for b in range(2):
         n = c[b]
@@ -316,5 +321,82 @@ def test_benchmark_batch_60_two_stage_forward():
         if c[b] > 0 and int(c4[b]) > 0:
             assert abs(float(d4[b, 0, 4]) - float(dets[b, 0, 4])) <= 2e-2
     assert c.sum() > 0
-    st = m.prefix_status
-    assert st.flagged() >= 0
+    assert m.prefix_status.flagged() == 0   # no image's top-nms_pre cut could have changed its result (as bench.py reports)
+
+
+def test_benchmark_batch_120_every_chunked_path():
+    """bench.py's default shape: R50-FPN 800x1344 at batch 120 in the stem layout -- the P2-level tensors are 4.1 GB, so md_conv2d, md_bottleneck,
+    md_conv1x1_dual and md_conv2d_head each run as TWO image chunks, and the stream / persistent / dual ping-pong kernels run at the
+    benchmark's grids.  Images 60..119 are copies of images 0..59, so image i sits in the first chunk and its copy in the second: every
+    output of the pair must be BIT-IDENTICAL (tile position, chunk and workgroup round cannot leak into a result).  Sampled images:
+    proposals and second stage bit-exact against the oracle from the device tensors at the stage boundary; prefix flags clear."""
+    from minddet.models import Config, build_detector
+    from minddet_amd import nn_ops
+    from minddet_amd.data import synthetic_images
+    from tests import stage_checks
+
+    cfg = Config.fromfile("configs/faster_rcnn/faster_rcnn_r50_fpn.py")
+    m = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(DEV)
+    half = nn_ops.to_stem_layout(synthetic_images(60, 800, 1344, seed=20240317, device=DEV))
+    x = torch.cat([half, half], 0).contiguous()
+    del half
+    dets, count, aux = m.forward(x, return_aux=True)
+    dets2, count2 = m.forward(x)
+    torch.cuda.synchronize()
+    assert dets.shape == (120, 100, 6) and count.shape == (120,)
+    assert torch.equal(dets, dets2) and torch.equal(count, count2)                       # deterministic
+    assert torch.equal(dets[:60], dets[60:]) and torch.equal(count[:60], count[60:])     # chunk / tile position independent
+    for f in aux["feats"]:
+        assert torch.equal(f[:60], f[60:])
+    assert torch.equal(aux["roi"]["pooled"][:60000], aux["roi"]["pooled"][60000:])
+    d, c = stage_checks.structure(dets, count, 100, (800, 1344))
+    assert c.sum() > 0
+    stage_checks.rpn_images(m, aux, (0, 59, 77, 119))
+    stage_checks.roi_images(m, aux, dets, count, (800, 1344), (0, 59, 77, 119))
+    assert m.prefix_status.flagged() == 0
+    del aux
+    # against the first 60 images alone (a batch of its own: other grids, other dispatcher choices on the unchunked layers -> last-bit
+    # bf16 differences upstream of every index): counts within 2, top scores within 1e-2 (measured r03: printed below)
+    d60, c60 = m.forward(x[:60].contiguous())
+    torch.cuda.synchronize()
+    cdiff = (c60.cpu() - count[:60].cpu()).abs().max().item()
+    both = (c60 > 0) & (count[:60] > 0)
+    sdiff = (d60[:, 0, 4] - dets[:60, 0, 4])[both].abs().max().item() if bool(both.any()) else 0.0
+    print("batch 60 alone vs inside the batch of 120: max count difference", cdiff, "max top-score difference", sdiff)
+    assert cdiff <= 2 and sdiff <= 1e-2
+
+
+def test_fused_block_and_dual_gemm_against_the_layer_by_layer_path():
+    """R50 backbone features with md_bottleneck + md_conv1x1_dual (the default) against the same weights layer by layer (FUSE_BLOCKS /
+    FUSE_DUAL off): md_bottleneck is bit-identical by construction; md_conv1x1_dual rounds the sum of conv3 and the downsample conv to
+    bf16 ONCE where the two-launch path rounds three times -> toleranced (rms of the difference <= 1 % of the feature rms per level).
+    Also the ADVICE r02 regression: after a weight change + .to() the fused packs must be rebuilt (they hold copies)."""
+    from minddet_amd import graphs, nn_ops
+
+    bb = graphs.ResNet(depth=50, seed=3).to(DEV)
+    g = torch.Generator().manual_seed(2)
+    x8 = torch.zeros((2, 128, 192, 8))
+    x8[..., :3] = torch.randn((2, 128, 192, 3), generator=g)
+    x = nn_ops.to_stem_layout(x8.to(torch.bfloat16).to(DEV))
+
+    def run(fuse):
+        old = graphs.FUSE_BLOCKS, graphs.FUSE_DUAL
+        graphs.FUSE_BLOCKS = graphs.FUSE_DUAL = fuse
+        try:
+            return [f.float() for f in bb(x)]
+        finally:
+            graphs.FUSE_BLOCKS, graphs.FUSE_DUAL = old
+
+    fused, plain = run(True), run(False)
+    assert torch.equal(fused[0], plain[0])          # stage 1: md_bottleneck only, bit-identical
+    for a, b in zip(fused[1:], plain[1:]):
+        rms = b.pow(2).mean().sqrt().item()
+        assert (a - b).pow(2).mean().sqrt().item() <= 1e-2 * rms
+    # change the weights of a stage-1 block and of a stage-2 first block, re-pack with .to(): the fused launches must see them
+    bb.stages[0][1].conv3.weight = bb.stages[0][1].conv3.weight * 0.5
+    bb.stages[1][0].downsample.weight = bb.stages[1][0].downsample.weight * 0.5
+    bb.to(DEV)
+    fused2, plain2 = run(True), run(False)
+    assert not torch.equal(fused2[0], fused[0]) and torch.equal(fused2[0], plain2[0])
+    for a, b in zip(fused2[1:], plain2[1:]):
+        assert (a - b).pow(2).mean().sqrt().item() <= 1e-2 * b.pow(2).mean().sqrt().item()

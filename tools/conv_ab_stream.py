@@ -29,23 +29,21 @@ for (H, W, Cin, Cout, res) in LAYERS:
     times = {a[0]: [] for a in arms}
     ref = nn_ops.conv2d(x, pc, residual=r, variant=20)
     for (nm, v, rd) in arms:
-        lib.md_conv2d_set_stream_rounds(rd)
-        assert torch.equal(nn_ops.conv2d(x, pc, residual=r, variant=v), ref), (nm, H, W, Cin, Cout)
+        assert torch.equal(nn_ops.conv2d(x, pc, residual=r, variant=v, tune=nn_ops.ConvTune(stream_rounds=rd)), ref), (nm, H, W, Cin, Cout)
     for rnd in range(7):
         for (nm, v, rd) in arms:
-            lib.md_conv2d_set_stream_rounds(rd)
+            tn = nn_ops.ConvTune(stream_rounds=rd)
             tt = 0.0
             for _ in range(3):
                 if FLUSH:
                     scratch.zero_()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                nn_ops.conv2d(x, pc, residual=r, variant=v, out=y)
+                nn_ops.conv2d(x, pc, residual=r, variant=v, out=y, tune=tn)
                 e1.record()
                 torch.cuda.synchronize()
                 tt += e0.elapsed_time(e1)
             times[nm].append(tt / 3)
-    lib.md_conv2d_set_stream_rounds(1)
     line = f"{b}x{H}x{W}x{Cin}->{Cout} k1{' +res' if res else ''}{' flushed' if FLUSH else ''}:"
     for (nm, v, rd) in arms:
         t = sorted(times[nm])[3]

@@ -1,5 +1,5 @@
 """md_conv1x1_dual (conv3 + strided downsample conv of a stage's first block as one GEMM) on the 128x128 kernel vs the ping-pong kernel
-(tools knob md_conv2d_set_dual_pp_min_k), interleaved, bit-compare.  python tools/dual_pp_ab.py [batch]"""
+(per-call knob md_conv_tune.dual_pp_min_k), interleaved, bit-compare.  python tools/dual_pp_ab.py [batch]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,23 +17,20 @@ for (Ho, Wo, Ca, Cb, Cout) in ((100, 168, 128, 256, 512), (50, 84, 256, 512, 102
     xa = torch.relu(torch.randn((B, Ho, Wo, Ca), generator=g)).to(torch.bfloat16).to(dev)
     xb = torch.relu(torch.randn((B, 2 * Ho, 2 * Wo, Cb), generator=g)).to(torch.bfloat16).to(dev)
     out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=dev)
-    lib.md_conv2d_set_dual_pp_min_k(1 << 30)
-    ref = nn_ops.conv1x1_dual(xa, xb, pk).clone()
-    lib.md_conv2d_set_dual_pp_min_k(128)
-    got = nn_ops.conv1x1_dual(xa, xb, pk)
+    T = {0: nn_ops.ConvTune(dual_pp_min_k=1 << 30), 1: nn_ops.ConvTune(dual_pp_min_k=128)}
+    ref = nn_ops.conv1x1_dual(xa, xb, pk, tune=T[0]).clone()
+    got = nn_ops.conv1x1_dual(xa, xb, pk, tune=T[1])
     kern = lib.md_conv2d_last_kernel()
     same = torch.equal(ref, got)
     times = {0: [], 1: []}
     for rnd in range(5):
         for arm in (0, 1):
-            lib.md_conv2d_set_dual_pp_min_k((1 << 30) if arm == 0 else 128)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(4):
-                nn_ops.conv1x1_dual(xa, xb, pk, out=out)
+                nn_ops.conv1x1_dual(xa, xb, pk, out=out, tune=T[arm])
             e1.record(); torch.cuda.synchronize()
             times[arm].append(e0.elapsed_time(e1) / 4)
-    lib.md_conv2d_set_dual_pp_min_k(768)
     t0, t1 = sorted(times[0])[2], sorted(times[1])[2]
     fl = 2.0 * B * Ho * Wo * Cout * (Ca + Cb)
     print(f"{B}x{Ho}x{Wo} [{Ca};{Cb}]->{Cout}: 128x128 {t0*1e3:7.1f} us ({fl/t0/1e9:5.0f} TF)  ping-pong {t1*1e3:7.1f} us ({fl/t1/1e9:5.0f} TF) kernel id {kern}  ratio {t0/t1:.3f}  identical={same}", flush=True)

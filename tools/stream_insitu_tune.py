@@ -22,12 +22,9 @@ def patched(xx, pc, residual=None, relu=None, out=None, variant=None, **kw):
     hit = pc.kh == 1 and (pc.cin, pc.cout) == cur["fam"]
     if hit:
         r, w, t = cur["knobs"]
-        lib.md_conv2d_set_stream_rounds(r); lib.md_conv2d_set_stream_tune(w, t)
+        kw["tune"] = nn_ops.ConvTune(stream_rounds=r, stream_wgs_per_cu=w, stream_cache_bits=8 | t)   # per-call knobs (md_conv_tune)
         variant = cur["variant"]
-    y = orig(xx, pc, residual=residual, relu=relu, out=out, variant=variant, **kw)
-    if hit:
-        lib.md_conv2d_set_stream_rounds(1); lib.md_conv2d_set_stream_tune(2, 6)
-    return y
+    return orig(xx, pc, residual=residual, relu=relu, out=out, variant=variant, **kw)
 
 nn_ops.conv2d = patched
 for _ in range(2):
