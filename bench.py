@@ -17,7 +17,7 @@ The JSON line also carries
   roofline     -- the DOMINANT conv kernel by time (md_conv2d_last_kernel attributes every launch; each is bracketed by
                   HIP events on the launch stream) against the roofline that binds its launches in aggregate
                   (algorithmic flops / 2.5 PFLOP/s dense bf16 or algorithmic bytes / 8 TB/s), its PMC traffic from
-                  profiles/r02_conv_traffic.json, and under "all_conv" the same per kernel and for the whole conv/FC set
+                  profiles/r03_conv_traffic.json (null when that file was measured on other kernel sources), and under "all_conv" the same per kernel and for the whole conv/FC set
                   (incl. frac_of_layerwise_roofline = sum of per-launch max(flops/peak, bytes/peak) / measured time).
   cpu_baseline -- the oracle's plain fp32 torch-CPU restatement of the same graph (oracle/nets.py) timed on this
                   host's cores on a bounded sample (rank 0, N=1 only).
@@ -91,12 +91,43 @@ def launch_ranks(args, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", MD_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + child_argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
+    # rank 0's pipe is drained by a thread (it can never fill), every child is polled: when one rank dies (OOM, bad LOCAL_RANK, RCCL
+    # init failure) the others would sit in the rendezvous or a collective until torch.distributed's timeout -- they are terminated
+    # instead (fresh child processes of this one; nothing is re-exec'ed), reaped, and the exit codes reported.  MD_BENCH_DEADLINE_S
+    # bounds the whole run.
+    import threading
+
+    out_buf = []
+    reader = threading.Thread(target=lambda: out_buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("MD_BENCH_DEADLINE_S", "3000"))
+    why, fail_rc = None, None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad or time.time() > deadline:
+            why = f"rank {bad[0]} exited with code {rcs[bad[0]]}" if bad else "deadline passed"
+            fail_rc = abs(rcs[bad[0]]) if bad else 124   # the code of the rank that died by itself, not of the siblings ended here
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.time() + 10.0
+            while time.time() < t_kill and any(p.poll() is None for p in procs):
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.1)
     rcs = [p.wait() for p in procs]
+    reader.join(10.0)
+    out0 = (out_buf[0] if out_buf else b"").decode()
     lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
-    if any(rcs) or len(lines) != 1:
-        sys.stderr.write(f"bench.py: rank exit codes {rcs}, {len(lines)} JSON line(s) from rank 0\n{out0}")
-        return max([abs(c) for c in rcs] + [1])
+    if why is not None or any(rcs) or len(lines) != 1:
+        sys.stderr.write(f"bench.py: {why + '; ' if why else ''}rank exit codes {rcs}, {len(lines)} JSON line(s) from rank 0\n{out0}")
+        return fail_rc if fail_rc else max([abs(c) for c in rcs if c] + [1])
     line = json.loads(lines[0])
     if line.get("n_gpus") != args.gpus:
         sys.stderr.write(f"bench.py: rank 0 reports n_gpus {line.get('n_gpus')}, expected {args.gpus}\n")
@@ -132,6 +163,9 @@ def make_step(model_forward, images, use_dist, gatherer=None, preprocess=None):
     return step, finish
 
 
+HOST_ENQUEUE = {"s": None}   # run_timed: host seconds spent enqueuing the K timed steps (before the closing device sync)
+
+
 def run_timed(step, finish, steps, warmup, use_dist, sync, barrier, all_reduce_max, before_timed=None, on_warmup=None):
     """W untimed warmup steps, then EXACTLY K steps bracketed by barrier + device sync on both sides; returns the MAX over ranks
     of the elapsed seconds (driver contract).  `on_warmup(i, step)` may replace the plain call of warmup step i."""
@@ -150,6 +184,7 @@ def run_timed(step, finish, steps, warmup, use_dist, sync, barrier, all_reduce_m
     for _ in range(steps):
         step()
     finish()
+    HOST_ENQUEUE["s"] = time.perf_counter() - t0   # the host is done enqueuing here; the device still runs (nothing above blocks on it)
     sync()
     if use_dist:
         barrier()
@@ -157,6 +192,18 @@ def run_timed(step, finish, steps, warmup, use_dist, sync, barrier, all_reduce_m
     if use_dist:
         dt = all_reduce_max(dt)
     return dt
+
+
+def kernel_source_hash():
+    """sha256 over the conv-family kernel sources: ties profiles/*_conv_traffic.json (separate rocprofv3 --pmc passes) to the build it
+    was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("conv.hip", "bottleneck.hip", "stem.hip", "stemconv.hip", "aot.h"):
+        with open(os.path.join(ROOT, "minddet_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def reference_ops_baseline(dev):
@@ -429,6 +476,7 @@ def main(argv=None):
                    lambda: dist.barrier(device_ids=[local_rank]), all_reduce_max, before_timed, on_warmup)
     instrument_off()
     survey = survey or None
+    host_enqueue_ms = None if HOST_ENQUEUE["s"] is None else HOST_ENQUEUE["s"] / max(args.steps, 1) * 1e3
 
     # the end-to-end figure from a resident uint8 batch (md_image_preprocess inside the step), next to the resident-layout one
     from_u8 = None
@@ -474,11 +522,17 @@ def main(argv=None):
         # layer-wise roofline: each launch is bounded by max(flops / MFMA peak, algorithmic bytes / HBM peak)
         t_roof_ms = sum(max(r[2] / (PEAK_BF16_TFLOPS * 1e12), r[6] / PEAK_HBM_BPS) for r in all_recs) * 1e3
         traffic = all_traffic = None
-        tp = os.path.join(ROOT, "profiles", "r02_conv_traffic.json")
+        traffic_note = "no PMC file for this library build"
+        tp = os.path.join(ROOT, "profiles", "r03_conv_traffic.json")
         PMC_PREFIX = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<256, 2, 2, 2, 2, 2,", 7: "bottleneck64_kernel", 8: "conv1x1_stream_kernel"}  # all instantiations of the kernel
         if os.path.exists(tp):  # PMC passes are separate rocprofv3 runs (tools/pmc_traffic.py); same config only
             tj = json.load(open(tp))
-            if tj.get("batch_per_gpu") == B and type(model).__name__ == "FasterRCNN":
+            # the PMC passes describe ONE build of the kernels: the file records the hash of the conv sources it was measured on
+            # (tools/pmc_traffic.py), and a line from any other build carries traffic = null instead of a stale figure
+            same_build = tj.get("kernel_source_sha256") == kernel_source_hash()
+            traffic_note = (f"rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{os.path.basename(tp)}" if same_build else
+                            f"profiles/{os.path.basename(tp)} was measured on other kernel sources: not reported")
+            if same_build and tj.get("batch_per_gpu") == B and type(model).__name__ == "FasterRCNN":
                 all_traffic = round(tj["hbm_bytes_per_launch"] / 1e6, 2)
                 pmc_rows = [v for k_, v in tj.get("by_kernel", {}).items() if dom in PMC_PREFIX and k_.startswith(PMC_PREFIX[dom])]
                 if pmc_rows:
@@ -488,7 +542,7 @@ def main(argv=None):
                     "bracketed": "HIP events around this kernel's launches in the timed region" + (
                         "; all_conv: every launch of the last warmup step" if survey else "; all_conv: every launch of the timed region"),
                     "achieved": round(ach, 2), "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "traffic_unit": "MB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_conv_traffic.json)",
+                    "traffic": traffic, "traffic_unit": "MB per launch (" + traffic_note + ")",
                     "achieved_tflops": round(d_fl / (d_ms * 1e-3) / 1e12, 2),
                     "algorithmic_mb_per_launch": round(d_by / d_n / 1e6, 2),
                     "algorithmic_gflop_per_launch": round(d_fl / d_n / 1e9, 1),
@@ -605,7 +659,11 @@ def main(argv=None):
             "metric": ("images/sec, Faster R-CNN R50-FPN inference, COCO-shaped 1333x800 (padded 800x1344)" if is_frcnn
                        else f"images/sec, {type(model).__name__} inference {H}x{W}"),
             "value": round(total_images / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            # host time per step spent ENQUEUING (Python + ctypes + launches) in the timed region, before the closing device sync: well
+            # under ms_per_step = the device is the bottleneck and N Python ranks on one node are not launch-bound
+            "host_enqueue_ms_per_step": None if host_enqueue_ms is None else round(host_enqueue_ms, 3),
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B,
                        "global_batch": world * B, "parallelism": f"dp{world} (image sharding + all_gather of detections)",

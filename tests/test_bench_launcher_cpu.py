@@ -44,7 +44,7 @@ def _stub_forward(rank, B, M):
     return fwd, calls
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, with_masks=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -52,8 +52,18 @@ def _worker(rank, world, port, q):
     from minddet_amd.shard import gather_detections_async
 
     B, M, K, W = 3, 5, 4, 2
-    fwd, calls = _stub_forward(rank, B, M)
-    step, finish = bench.make_step(fwd, torch.zeros(1), True, lambda out: gather_detections_async(out[0], out[1], force=True))
+    fwd0, calls = _stub_forward(rank, B, M)
+    fwd = fwd0
+    if with_masks:   # the Mask R-CNN form: a third output travels in a second fixed-shape all_gather (fp16 28x28 masks)
+        def fwd(x):
+            d_, c_ = fwd0(x)
+            mk = torch.zeros((B, M, 28, 28))
+            for b in range(B):
+                mk[b, :, 0, 0] = float(rank * B + b)
+                mk[b, :, 1, 1] = float(calls["n"])
+            return d_, c_, mk
+    step, finish = bench.make_step(fwd, torch.zeros(1), True,
+                                   lambda out: gather_detections_async(out[0], out[1], masks=out[2] if len(out) > 2 else None, force=True))
 
     def all_reduce_max(v):
         t = torch.tensor([v], dtype=torch.float64)
@@ -63,8 +73,14 @@ def _worker(rank, world, port, q):
     t_own0 = time.perf_counter()
     dt = bench.run_timed(step, finish, K, W, True, lambda: None, dist.barrier, all_reduce_max)
     t_own = time.perf_counter() - t_own0
-    d, c = finish()
+    res = finish()
+    d, c = res[0], res[1]
     ok = calls["n"] == K + W                                   # exactly K timed + W warmup forward passes
+    if with_masks:
+        mk = res[2]
+        ok = ok and mk.dtype == torch.float16 and mk.shape == (world * B, M, 28, 28)
+        ok = ok and bool((mk[:, 0, 0, 0] == torch.arange(world * B, dtype=torch.float16)).all()) and bool((mk[:, :, 1, 1] == K + W).all())
+    ok = ok and bench.HOST_ENQUEUE["s"] is not None and 0 < bench.HOST_ENQUEUE["s"] <= t_own
     ok = ok and d.shape == (world * B, M, 6) and c.tolist() == [g % (M + 1) for g in range(world * B)]   # input order
     for g in range(world * B):
         n = int(c[g])
@@ -74,19 +90,34 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_bench_step_and_timing_code_world2_gloo():
+def _run_world(world, with_masks):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, with_masks)) for r in range(world)]
     for p in ps:
         p.start()
     res = sorted(q.get(timeout=180) for _ in ps)
     for p in ps:
         p.join(60)
     assert all(ok for _, ok, _, _ in res), res
-    # every rank reports the same (max-over-ranks) time, and it covers the slow rank's 4 x 20 ms of "compute"
-    assert abs(res[0][2] - res[1][2]) < 1e-9 and res[0][2] >= 4 * 0.02 * 0.9 and res[0][2] <= res[1][3]
+    # every rank reports the same (max-over-ranks) time, and it covers the SLOWEST rank's 4 x (10 ms x world) of "compute"
+    assert all(abs(r[2] - res[0][2]) < 1e-9 for r in res) and res[0][2] >= 4 * 0.01 * world * 0.9 and res[0][2] <= res[-1][3]
+
+
+def test_bench_step_and_timing_code_world2_gloo():
+    _run_world(2, False)
+
+
+def test_bench_step_and_timing_code_world4_unequal_speeds_gloo():
+    """four ranks whose forward passes take 10 / 20 / 30 / 40 ms: the async gather of step i is joined behind step i + 1 on every rank
+    without deadlock, the last step's detections arrive in input order everywhere, the reported time is the slowest rank's"""
+    _run_world(4, False)
+
+
+def test_bench_two_gather_form_world2_gloo():
+    """Mask R-CNN: detections + a second fixed-shape all_gather of the fp16 28x28 masks through the same make_step / run_timed code"""
+    _run_world(2, True)
 
 
 def test_async_gather_single_process_is_identity():
@@ -134,6 +165,11 @@ def test_launcher_relays_exactly_one_line(tmp_path, monkeypatch):
         "assert os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and '--spawn' not in sys.argv\n"
         "mode = os.environ.get('CHILD_MODE', 'ok')\n"
         "if mode == 'fail' and r == 1: sys.exit(3)\n"
+        "if mode == 'die' and r == 2: sys.exit(7)\n"
+        "if mode in ('die', 'hang'):\n"
+        "    import time\n"
+        "    if r == 0: print('rank 0 is waiting in a collective', flush=True)\n"
+        "    time.sleep(600)\n"
         "if r == 0: print(json.dumps({'n_gpus': w if mode != 'wrong' else 1, 'value': 1.0}))\n")
     monkeypatch.setattr(bench, "__file__", str(child))
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
@@ -151,3 +187,18 @@ def test_launcher_relays_exactly_one_line(tmp_path, monkeypatch):
         with redirect_stdout(buf):
             rc = bench.launch_ranks(args, ["--gpus", "3"])
         assert rc != 0 and buf.getvalue() == ""
+    # one rank dies while the others sit in a "collective" (sleep 600): the launcher terminates and reaps the siblings and returns the
+    # dead rank's code at once, not after torch.distributed's timeout; a run past MD_BENCH_DEADLINE_S is ended the same way
+    import psutil
+
+    for mode, want in (("die", 7), ("hang", None)):
+        monkeypatch.setenv("CHILD_MODE", mode)
+        monkeypatch.setenv("MD_BENCH_DEADLINE_S", "3" if mode == "hang" else "3000")
+        t0 = time.time()
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            rc = bench.launch_ranks(args, ["--gpus", "3"])
+        assert rc != 0 and (want is None or rc == want) and buf.getvalue() == "" and time.time() - t0 < 60
+        left = [c for c in psutil.Process().children(recursive=True) if c.is_running() and c.status() != psutil.STATUS_ZOMBIE
+                and any(str(child) in a for a in c.cmdline())]
+        assert not left, left

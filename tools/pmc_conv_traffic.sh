@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC traffic of every conv launch of a bench.py config: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; the guide's
 # HBM section: they cannot share a pass, and no tracing domain next to --pmc) -> <out>.json via tools/pmc_traffic.py.
-# usage (repo root, GPU box): bash tools/r02_pmc.sh <out.json> <batch> [bench.py args...]
+# usage (repo root, GPU box): bash tools/pmc_conv_traffic.sh <out.json> <batch> [bench.py args...]
 set -e -o pipefail
 OUT=$1; BATCH=$2; shift 2
 export TMPDIR=/tmp

@@ -37,5 +37,10 @@ for k in conv:
     d[0] += fetch[k][0]; d[1] += write[k][0]; d[2] += fetch[k][1]
 out["by_kernel"] = {n_: {"launches": d[2], "FETCH_SIZE_KB_raw": d[0], "WRITE_SIZE_KB": d[1],
                          "hbm_bytes_per_launch": (2.0 * d[0] + d[1]) * 1024 / d[2]} for n_, d in by.items()}
+# the build these counters describe: bench.py reports traffic only when the kernel sources it runs hash to the same value
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+out["kernel_source_sha256"] = bench.kernel_source_hash()
 json.dump(out, open(sys.argv[5], "w"), indent=1)
 print(out)
