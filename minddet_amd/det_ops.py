@@ -188,6 +188,10 @@ def nms_aligned(boxes_sorted, thresh, eps=0.0, mode=NMS_MODE_JIT, count=None, gr
     if group is not None:
         group = group.to(device=dev, dtype=torch.int32).contiguous()
     params = [b, count, group, mask, idx, num]
+    if workspace is None and B * n > 0:
+        # suppression-mask scratch from torch's caching allocator (never blocks), not from the op's hipMallocAsync fallback
+        cb = (n + 63) // 64
+        workspace = torch.empty((B * n * cb * 8 + (B * 4 + 255) // 256 * 256,), dtype=torch.uint8, device=dev)
     if workspace is not None:
         params.append(workspace)
     _lib.call("md_nms_aligned", params, extra=_NmsAttrs(float(thresh), float(eps), int(mode), int(max_output)))
@@ -402,9 +406,16 @@ def topk_segmented(scores, seg_offsets, k, min_score=None, out_cnt=None, max_seg
     vals = torch.empty((L, k), dtype=torch.float32, device=scores.device)
     idx = torch.empty((L, k), dtype=torch.int32, device=scores.device)
     cnt = out_cnt if out_cnt is not None else torch.empty((L,), dtype=torch.int32, device=scores.device)
-    _lib.call("md_topk_segmented", [scores, seg_offsets, vals, idx, cnt],
-              extra=_TopkAttrs(int(k), -FLT_MAX if min_score is None else float(min_score),
-                               int(scores.numel() if max_segment is None else max_segment)))
+    max_segment = int(scores.numel() if max_segment is None else max_segment)
+    params = [scores, seg_offsets, vals, idx, cnt]
+    if max_segment > 4 * 8192 and k <= 4096 and L <= 65535:
+        # the multi-workgroup select takes scratch: hand it a block of torch's caching allocator.  Without it the op falls back to
+        # hipMallocAsync / hipFreeAsync, which BLOCKED the host ~7 ms per call on ROCm 7.2 (r03 tools/host_enqueue.py: 49.6 of the
+        # 51.9 ms the host spent enqueuing one Faster R-CNN step sat in these seven calls, the device queue running dry behind each)
+        hist = ((L * (2048 * 4 + 4)) + 255) // 256 * 256
+        params.append(torch.empty((hist + L * 8192 * 8,), dtype=torch.uint8, device=scores.device))
+    _lib.call("md_topk_segmented", params,
+              extra=_TopkAttrs(int(k), -FLT_MAX if min_score is None else float(min_score), max_segment))
     return vals, idx, cnt
 
 
