@@ -91,6 +91,8 @@ struct ConvArgs {
     unsigned x2_bytes;
     int H2, W2, Xs2, stride2, nk_a;
     int tune;               // conv1x1_stream_kernel cache-policy bits (md_conv_tune.stream_cache_bits): 1 = x DMA nt, 2 = residual DMA nt, 4 = stores nt
+    int tiles_x, tiles_y;   // HALO form of the ping-pong kernel: 16 x 16-pixel tiles per image row / rows of such tiles
+    int tiles_strip;        // HALO: 8 x 32-pixel tiles of the bottom strip (image rows 16 * tiles_y ..; 0 = none), tiles per image = tiles_x * tiles_y + tiles_strip
     int Rs;                 // 0: the residual has the output's layout; > 0: residual pixel m, channel c at m*Rs + c (a channel
                             // slice of a wider [N,Ho,Wo,Rs] tensor, a.res pointing at its first channel)
 };
@@ -1112,19 +1114,33 @@ struct KWalk { int tap, kh, kw, cc0; };
 // PERS (GEN 0 / 2, no residual, plain or concat output): PERSISTENT form -- one workgroup per CU walks over several pixel tiles; the seven
 // prologue half tiles of the NEXT tile are requested before the current tile's epilogue, which runs barrier-free through wave-private
 // 2.5-KiB LDS slabs (the staging buffers stay free for the DMA stream) and leaves as buffer stores.
-template <int ABL, int MF = 0, int GEN = 1, bool HEAD = false, bool PERS = false>  // GEN as in conv_igemm_kernel; HEAD: fused 1x1 head; ABL 0: product; timing ablations (wrong results): 1 no in-loop staging, 2 no output stores, 4 stamps
+// HALO (3x3 / stride 1 / pad 1, korder-1 weights, GEN 0 / 2; r03): the pixel tile is a 16 x 16 block of ONE image (an 8 x 32 block in the
+// bottom strip of an image whose height leaves at most 8 rows past the 16-row tiles: 200 x 336 is covered with 0.2 % idle pixels) and its
+// 18 x 18 (10 x 34) x 64-channel halo is staged ONCE per channel chunk (41 / 43 pieces of 1 KiB, two buffers alternating by chunk parity); the
+// nine taps of the chunk = nine K tiles read their B fragments out of it with shifted rows.  The B stream drops from 32 KiB to 4.6 KiB per K
+// tile (8 -> 5 LDS-DMA pieces per wave and K tile, the fifth being a halo piece or -- K tiles 6-8 of a chunk, pieces past the halo -- a 1-KiB
+// zero fill of a dummy area, so that every K tile issues the same number and the counted waits stay immediates: vmcnt(5)).  Same K order, same
+// MFMA sequence per output element as the linear-tile form: bit-identical results.
+// LDS (HALO): A halves [0, 64K) = {parity} x {A0, A1}; halo buffers [64K, 107K), [107K, 150K); dummy 1K; bias 1K; W2 8K (HEAD) = 160 KiB.
+constexpr int HB_ROWS = 344 /* 18 x 18 = 324 or 10 x 34 = 340 halo pixels, in whole pieces (8 rows) */, HB_BYTES = HB_ROWS * ROWB, HB0_OFF = 4 * 128 * ROWB, HB_DUMMY = HB0_OFF + 2 * HB_BYTES, HB_BIAS = HB_DUMMY + 1024,
+              HB_W2 = HB_BIAS + 256 * 4, HB_LDS = HB_W2, HB_LDS_HEAD = HB_W2 + 16 * 256 * 2;
+template <int ABL, int MF = 0, int GEN = 1, bool HEAD = false, bool PERS = false, bool HALO = false>  // GEN as in conv_igemm_kernel; HEAD: fused 1x1 head; ABL 0: product; timing ablations (wrong results): 1 no in-loop staging, 2 no output stores, 4 stamps
 __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     static_assert(!PERS || (!HEAD && ABL == 0 && GEN != 1), "the persistent form has the plain epilogues only");
+    static_assert(!HALO || (ABL == 0 && GEN != 1), "the halo form has the plain epilogues only");
     constexpr int CT = 256, PT = 256, NT = 512;
     constexpr int EP_STRIDE = CT * 2 + 16;
     constexpr unsigned OOR = 0x80000000u;
-    constexpr int H_A0 = 0, H_B0 = 1, H_B1 = 2, H_A1 = 3;
+    constexpr int H_A0 = 0, H_B0 = 1, H_B1 = 2, H_A1 = HALO ? 1 : 3;
+    constexpr int A_SLOTS = HALO ? 2 : 4;   // half-tile slots per K-tile parity
     typedef __attribute__((address_space(3))) void lds_void;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int l16 = lane & 15, lq = lane >> 4;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int ct = slot % a.n_ctiles;
     int ptl = slot / a.n_ctiles;                                        // pixel tile inside the XCD's range
@@ -1137,7 +1153,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     if (ABL == 4) clk_start = __builtin_readcyclecounter();
     // bias: requested now, parked in LDS past the epilogue image after the prologue wait (see conv_igemm_kernel)
     const float bias_early = tid < CT ? a.bias[cout0 + tid] : 0.f;
-    float *bias_lds = reinterpret_cast<float *>(smem + (PERS ? 8 * 128 * ROWB : PT * EP_STRIDE));   // PERS: right behind the 128 KiB of staging buffers
+    float *bias_lds = reinterpret_cast<float *>(smem + (HALO ? HB_BIAS : (PERS ? 8 * 128 * ROWB : PT * EP_STRIDE)));   // PERS: right behind the 128 KiB of staging buffers
 
     __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
@@ -1151,7 +1167,45 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     int p_base[4];       // [hB * 2 + i]: byte offset of (n, hi0, wi0, chunk) of the staged pixel row
     unsigned p_taps[4];  // tap-validity bits (0 past M)
     unsigned p_base2[4]; // DUAL (a.x2 != null: md_conv1x1_dual): the row's pixel in the second tensor, sampled with a.stride2 (OOR past M)
+    // HALO: image / top-left pixel / shape of the tile (t_twl = log2 of its width: 4 = 16 x 16, 5 = 8 x 32 of the bottom strip; t_hw = halo
+    // width, t_magic: r / t_hw == (r * t_magic) >> 16 for r < 400), and this lane's byte offset into x for each of the wave's six halo pieces
+    // (piece wave + 8 j = halo rows 8 * piece .. + 7, row r = halo pixel (r / t_hw, r % t_hw); OOR outside the image = the conv's zero padding)
+    int t_n = 0, t_y0 = 0, t_x0 = 0, t_twl = 4, t_hw = 18, t_magic = 3641, t_hpix = 324;
+    int hpb[4] = {0, 0, 0, 0};   // halo row of this lane's pixel for tap (0, 0): MF 1 one per 16-pixel fragment of the wave's four, MF 0 one per pixel half
+    // (computed where a piece is issued, ~18 VALU per K tile: six precomputed offsets selected by the wave-uniform piece index ended up in
+    // SCRATCH -- hipcc lowers the select chain to an indexed private-memory load, a vector-memory operation inside the K loop that
+    // would also count in vmcnt)
+    const int nch = a.Cin >> 6;
+    auto piece_off = [&](int j, int c) -> unsigned {
+        const int r = (wave + 8 * j) * 8 + (lane >> 3);
+        const int hy = (r * t_magic) >> 16, hx = r - hy * t_hw;
+        const int iy = t_y0 - 1 + hy, ix = t_x0 - 1 + hx;
+        // the 16-B chunk swizzle is taken on the row's ABSOLUTE LDS row (the fragment reads fold the buffer base into the row index): buffer
+        // 1 starts HB_ROWS = 344 rows (an odd multiple of 8) behind buffer 0, which flips bit 2 of (row >> 1) & 7
+        const int lchunk = (lane & 7) ^ ((r >> 1) & 7) ^ ((c & 1) << 2);
+        const bool ok = r < t_hpix && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        return ok ? (unsigned)((((t_n * a.H + iy) * a.W + ix) * a.Xs + lchunk * 8) * 2) : OOR;
+    };
     auto setup_tile = [&]() {
+    if constexpr (HALO) {
+        const int pt = xcd * a.pt_per_xcd + ptl, full = a.tiles_x * a.tiles_y, per = full + a.tiles_strip;
+        t_n = pt / per;
+        const int rr = pt - t_n * per;
+        if (rr < full) {
+            const int ty = rr / a.tiles_x;
+            t_y0 = ty * 16; t_x0 = (rr - ty * a.tiles_x) * 16;
+            t_twl = 4; t_hw = 18; t_magic = 3641; t_hpix = 324;
+        } else {   // the bottom strip: 8 x 32 tiles
+            t_y0 = a.tiles_y * 16; t_x0 = (rr - full) * 32;
+            t_twl = 5; t_hw = 34; t_magic = 1928; t_hpix = 340;
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int pl = MF ? wc * 64 + r4 * 16 + l16 : wc * 64 + (r4 & 1) * 32 + lr;   // tile-local pixel of this lane in the fragment
+            hpb[r4] = (pl >> t_twl) * t_hw + (pl & ((1 << t_twl) - 1));
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int hB = q >> 1, i = q & 1;
@@ -1193,7 +1247,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     };
     auto stage_A = [&](int kt, int hA, int hbuf) {
         if (ABL == 1 && kt >= 2) return;
-        char *dst = smem + ((kt & 1) * 4 + hbuf) * PP_HALF + wave * (8 * ROWB);
+        char *dst = smem + ((kt & 1) * A_SLOTS + hbuf) * PP_HALF + wave * (8 * ROWB);
         const unsigned dead = (unsigned)((nk - 1 - kt) >> 31) << 31;  // 2^31 for the tiles past the end: out of range, zero fill
         const int ktc = kt < nk ? kt : nk - 1;
 #pragma unroll
@@ -1221,6 +1275,18 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         }
     };
 
+    // HALO: piece (wave + 8 j) of channel chunk c's halo -> buffer c & 1; pieces past the 41st and chunks past the end are a zero fill of
+    // the 1-KiB dummy area (same instruction count in every K tile).  j is wave-uniform: the select chain costs five v_cndmask.
+    auto stage_H = [&](int c, int j) {
+        if constexpr (HALO) {
+            const int piece = wave + 8 * j;
+            const bool real = j < 6 && piece < HB_ROWS / 8 && c < nch;
+            const unsigned off = piece_off(j < 6 ? j : 5, c);
+            char *dst = smem + (real ? HB0_OFF + (c & 1) * HB_BYTES + piece * 1024 : HB_DUMMY);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)dst, 16, (int)(real ? off : OOR), (c < nch ? c : 0) * (BK * 2), 0, 0);
+        }
+    };
+
     f32x16 acc[MF ? 1 : 4][MF ? 1 : 2];
     f32x4 acc4[MF ? 8 : 1][MF ? 4 : 1];  // MF 1: [16-row fragment of the wave's 128 couts][16-pixel fragment of its 64 pixels]
     auto zero_acc = [&]() {
@@ -1240,14 +1306,14 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     };
     zero_acc();
 
-    const int lr = lane & 31, lh = lane >> 5;
-    const int l16 = lane & 15, lq = lane >> 4;
     int fa_off[4], fb_off[4];  // per k-step fragment offsets inside a half tile (MF 1 uses two: K 32 per step)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         fa_off[kk] = MF ? swz(wr * 64 + l16, (kk & 1) * 4 + lq) : swz(wr * 64 + lr, kk * 2 + lh);
         fb_off[kk] = MF ? swz(wc * 32 + l16, (kk & 1) * 4 + lq) : swz(wc * 32 + lr, kk * 2 + lh);
     }
+    // HALO: the lane's k-chunk bits in address position
+    const int hkq = MF ? (lq << 4) : (lh << 4);
     // operand registers of a phase: MF 0 fa[row fragment 0-1][k step 0-3], fb[pixel half][k step];
     //                               MF 1 fa[r][s] = row fragment (2r + (s >> 1)), k step (s & 1); fb[h][s] likewise per pixel half
     bf16x8 fa[2][4], fb[2][4];
@@ -1270,7 +1336,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);                                        \
     PP_STAMP((I0) * 5 / 2 + 1)                                                \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        \
-    if (ABL != 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            \
+    if (ABL != 1) { if (HALO) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } \
     PP_STAMP((I0) * 5 / 2 + 2)                                                \
     __builtin_amdgcn_s_barrier();                                             \
     PP_STAMP((I0) * 5 / 2 + 3)                                                \
@@ -1302,7 +1368,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 
     // HEAD: the 16 x 256 head weights -> LDS (8 KiB above the bias copy), one 1-KiB DMA per wave; lane -> (row, physical
     // 16-B chunk), logical chunk = physical ^ row so that the 16 rows of an A-fragment read fall on 16 different slots
-    constexpr int W2_OFF = PT * EP_STRIDE + CT * 4;
+    constexpr int W2_OFF = HALO ? HB_W2 : PT * EP_STRIDE + CT * 4;
     if constexpr (HEAD) {
         __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2, 0, 16 * 256 * 2, 0x00020000);
         const int i = wave * 64 + lane, row = i >> 5, phys = i & 31;
@@ -1311,6 +1377,15 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     // ---- prologue: tile 0 and the A0/B0/B1 halves of tile 1 (seven half tiles)
     KWalk w2 = {0, 0, 0, 0};
     auto issue_prologue = [&]() {
+        if constexpr (HALO) {
+            // chunk 0's halo, K tile 0's A halves, then "phase 1 of K tile -1" (A0 of K tile 1 + one dummy piece): from here on every phase
+            // issues what it issues in the steady state, so one immediate (vmcnt 5 = the two youngest phases' pieces) serves every wait
+#pragma unroll
+            for (int j = 0; j < 6; ++j) stage_H(0, j);
+            stage_A(0, 0, H_A0); stage_A(0, 1, H_A1);
+            stage_A(1, 0, H_A0); stage_H(nch, 0);
+            return;
+        }
         KWalk w0 = {0, 0, 0, 0}, w1 = w0;
         walk_next(w1);
         w2 = w1;
@@ -1322,11 +1397,12 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     bool first_tile = true;
     for (;;) {   // one pass unless PERS
     if (!PERS || first_tile) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // also retires the (older) bias load
+        // also retires the (older) bias load.  HALO: 13 pieces issued, the first 8 (halo + A0 / A1 of K tile 0) needed now
+        if (HALO) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         if (tid < CT) bias_lds[tid] = bias_early;         // read in the epilogue, hundreds of barriers later
     } else {
         // behind the seven prologue half tiles (14 DMAs, the first 6 needed now) sit the 16 stores of the previous tile's epilogue
-        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        if (HALO) asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs half a phase behind group 0
@@ -1334,14 +1410,38 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 
     unsigned long long clk0 = 0, rt0 = 0;
     if (ABL == 4) { clk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    int s_tap = 0, s_dy = 0, s_dx = 0, s_ct = 0;   // HALO: tap / channel chunk of K tile t (K = (chunk, tap, channel in chunk))
     for (int t = 0; t < nk; ++t) {
-        const char *T = smem + (t & 1) * (4 * PP_HALF);
+        const char *T = smem + (t & 1) * (A_SLOTS * PP_HALF);
         PP_STAMP(0)
         // phase 0: cout rows 0-63 of the wave x its 64 pixels
+        if constexpr (HALO) {
+            // B fragments out of the chunk's halo: row = the pixel's halo row shifted by the tap, 16-B chunk XOR (row >> 1) & 7 as staged.
+            // The buffer's base (a multiple of 16 rows) rides in the row index: the swizzle bits are unchanged by it.
+            const int s_row = s_dy * t_hw + s_dx + (HB0_OFF / ROWB) + (s_ct & 1) * HB_ROWS;
+            if constexpr (MF == 1) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int pr = hpb[r4] + s_row;
+                    const int ad = (pr << 7) + ((((pr << 3) & 0x70)) ^ hkq);
+                    fb[r4 >> 1][(r4 & 1) * 2 + 0] = *reinterpret_cast<const bf16x8 *>(smem + ad);
+                    fb[r4 >> 1][(r4 & 1) * 2 + 1] = *reinterpret_cast<const bf16x8 *>(smem + (ad ^ 64));
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int pr = hpb[h] + s_row;
+                    const int ad = (pr << 7) + ((((pr << 3) & 0x70)) ^ hkq);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) fb[h][kk] = *reinterpret_cast<const bf16x8 *>(smem + (ad ^ (kk << 5)));
+                }
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             fb[0][kk] = *reinterpret_cast<const bf16x8 *>(T + H_B0 * PP_HALF + fb_off[kk] + (MF ? (kk >> 1) * 16 * ROWB : 0));
             fb[1][kk] = *reinterpret_cast<const bf16x8 *>(T + H_B1 * PP_HALF + fb_off[kk] + (MF ? (kk >> 1) * 16 * ROWB : 0));
+        }
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -1359,7 +1459,9 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
             fa[0][kk] = *reinterpret_cast<const bf16x8 *>(T + H_A1 * PP_HALF + fa_off[kk] + (MF ? (kk >> 1) * 16 * ROWB : 0));
             fa[1][kk] = *reinterpret_cast<const bf16x8 *>(T + H_A1 * PP_HALF + fa_off[kk] + 32 * ROWB + (MF ? (kk >> 1) * 16 * ROWB : 0));
         }
-        stage_A(t + 2, 0, H_A0); stage_B(t + 2, 0, H_B0, w2); stage_B(t + 2, 1, H_B1, w2);
+        stage_A(t + 2, 0, H_A0);
+        if constexpr (HALO) stage_H(s_ct + 1, s_tap);   // one piece of the NEXT chunk's halo per K tile (pieces 6-8: the dummy fill)
+        else { stage_B(t + 2, 0, H_B0, w2); stage_B(t + 2, 1, H_B1, w2); }
         PP_SYNC_LOADS(2)
         PP_MFMA(2)
         PP_END_PHASE(2)
@@ -1368,7 +1470,10 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 11; ++i) keep[i] = st[i];
         }
-        walk_next(w2);
+        if constexpr (HALO) {
+            if (++s_dx == 3) { s_dx = 0; ++s_dy; }
+            if (++s_tap == 9) { s_tap = 0; s_dy = 0; ++s_ct; }
+        } else walk_next(w2);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();  // every wave has now passed 2 + 4 nk barriers
     unsigned long long clk1 = 0, rt1 = 0;
@@ -1383,7 +1488,9 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     if constexpr (PERS) {
         // ---- persistent form: request the next tile's prologue NOW (every wave is past its last fragment read), then run this tile's
         // epilogue out of the registers through the wave's private slab -- builtin vector types only (see conv1x1_stream_kernel)
-        const int pix_cur = pix0;
+        // HALO: the tile's first pixel (its top-left corner); the wave's pixels are rows / columns of the 16 x 16 block behind it
+        const int pix_cur = HALO ? (t_n * a.H + t_y0) * a.W + t_x0 : pix0;
+        const int cur_y0 = t_y0, cur_x0 = t_x0, cur_twl = t_twl;
         ptl += pstep;
         const bool more = ptl < a.pt_per_xcd && xcd * a.pt_per_xcd + ptl < a.n_ptiles;
         if (more) {
@@ -1391,7 +1498,9 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
             setup_tile();
             issue_prologue();
         }
-        char *slab = smem + 8 * 128 * ROWB + CT * 4 + wave * 2560;
+        // (HALO: the slabs sit in halo buffer 1 -- its last reader was a K tile of this tile, its next writer is a piece issued inside the
+        // next tile's loop, behind that tile's opening barrier)
+        char *slab = smem + (HALO ? HB0_OFF + HB_BYTES : 8 * 128 * ROWB + CT * 4) + wave * 2560;
         const long long rem = ((long long)a.M - pix_cur) * a.Ctot * 2 - (a.c_off + cout0) * 2;
         __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + (size_t)pix_cur * a.Ctot + a.c_off + cout0), 0,
                                                                         (int)(rem > 0x7fffffffLL ? 0x7fffffffLL : rem), 0x00020000);
@@ -1404,6 +1513,13 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(slab + (e_px + 8 * it) * 144 + e_ch * 16);
+                if constexpr (HALO) {   // tile-local pixel -> (row, column) by the tile's shape; outside the image: dropped by the range check
+                    const int pl = wc * 64 + px0 + 8 * it + e_px;
+                    const int row = pl >> cur_twl, col = pl & ((1 << cur_twl) - 1);
+                    const bool ok = cur_y0 + row < a.H && cur_x0 + col < a.W;
+                    const unsigned off = ok ? (unsigned)(((row * a.W + col) * a.Ctot + wr * 128 + e_ch * 8) * 2) : OOR;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, (int)off, c0 * 2, 2);
+                } else
                 __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, v_io + (px0 + 8 * it) * row_b, c0 * 2, 2);
             }
         };
@@ -1521,7 +1637,12 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         const float4 hb = *reinterpret_cast<const float4 *>(a.b2 + 4 * lq);
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            const int m = pix0 + wave * 32 + f * 16 + l16;
+            int m = pix0 + wave * 32 + f * 16 + l16;
+            if constexpr (HALO) {   // tile-local pixel wave * 32 + f * 16 + l16
+                const int pl = wave * 32 + f * 16 + l16;
+                const int yy = t_y0 + (pl >> t_twl), xx = t_x0 + (pl & ((1 << t_twl) - 1));
+                m = (yy < a.H && xx < a.W) ? (t_n * a.H + yy) * a.W + xx : a.M;
+            }
             if (m >= a.M) continue;
             uint2 pk;
             pk.x = pk_bf16(h[f][0] + hb.x, h[f][1] + hb.y);
@@ -1544,12 +1665,19 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         const int Hr = (a.Ho + 1) >> 1, Wr = (a.Wo + 1) >> 1;
         return (((size_t)n * Hr + (ho >> 1)) * Wr + (wo >> 1)) * a.Cout + c;
     };
+    auto tile_pixel = [&](int p_local) -> int {   // output pixel index of the tile's pixel p_local (a.M: outside the image)
+        if constexpr (HALO) {
+            const int yy = t_y0 + (p_local >> t_twl), xx = t_x0 + (p_local & ((1 << t_twl) - 1));
+            return (yy < a.H && xx < a.W) ? (t_n * a.H + yy) * a.W + xx : a.M;
+        }
+        return pix0 + p_local;
+    };
     u32x4 rres[EP_ITERS];
     if (a.res) {
 #pragma unroll
         for (int it = 0; it < EP_ITERS; ++it) {
             const int e = tid + it * NT;
-            const int m = pix0 + e / CPP, c = cout0 + (e % CPP) * 8;
+            const int m = tile_pixel(e / CPP), c = cout0 + (e % CPP) * 8;
             rres[it] = (u32x4){0u, 0u, 0u, 0u};
             if (m < a.M) rres[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + res_offset(m, c)));
         }
@@ -1558,7 +1686,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     for (int it = 0; it < EP_ITERS; ++it) {
         const int e = tid + it * NT;
         const int p_local = e / CPP, cc = e % CPP;
-        const int m = pix0 + p_local, c = cout0 + cc * 8;
+        const int m = tile_pixel(p_local), c = cout0 + cc * 8;
         if (m >= a.M) continue;
         u32x4 v = *reinterpret_cast<const u32x4 *>(E + p_local * EP_STRIDE + cc * 16);
         if (a.res) {
@@ -1594,36 +1722,59 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 // +1.6 %, 50x84: +0.9 %) and a lower one on the short-K / small-grid layers (1x1 1024->256: -7 %, 3x3 512->512 at 25x42: -3 %).
 static bool pingpong_wants_16x16(const ConvArgs &a) { return a.kh == 3 && a.kw == 3 && a.Kpad >= 2304 && a.M >= 400000; }
 
-template <int MF>
+// The HALO form's tile map: 16 x 16-pixel tiles, row-major per image (neighbouring tiles -- which share halo columns -- sit on one XCD).
+static long long pingpong_halo_tiles_per_image(int H, int W, int *tiles_y, int *tiles_strip) {
+    const int rem = H % 16;
+    const bool strip = rem > 0 && rem <= 8;   // at most 8 rows left under the 16-row tiles: a strip of 8 x 32 tiles instead of half-empty 16 x 16 ones
+    const int ty = strip ? H / 16 : (H + 15) / 16, ts = strip ? (W + 31) / 32 : 0;
+    if (tiles_y) *tiles_y = ty;
+    if (tiles_strip) *tiles_strip = ts;
+    return (long long)ty * ((W + 15) / 16) + ts;
+}
+static void pingpong_halo_tiles(ConvArgs &a) {
+    a.tiles_x = (a.W + 15) / 16;
+    a.n_ptiles = (int)(a.N * pingpong_halo_tiles_per_image(a.H, a.W, &a.tiles_y, &a.tiles_strip));
+    a.pt_per_xcd = (a.n_ptiles + 7) / 8;
+}
+// Preconditions of the HALO form (checked by the dispatcher besides the ping-pong kernel's own): 3x3 / stride 1 / pad 1 with korder-1 weights.
+static bool pingpong_halo_takes(const ConvArgs &a) {
+    return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad_top == 1 && a.pad_left == 1 && a.korder == 1 && a.Cin % 64 == 0 && a.Ho == a.H &&
+           a.Wo == a.W && !a.x2 && !a.res_up && a.x_bytes != 0 && (long long)a.N * pingpong_halo_tiles_per_image(a.H, a.W, nullptr, nullptr) < 0x7fffffffLL / 8;
+}
+
+template <int MF, bool HALO>
 static int launch_conv_pingpong_head_mf(ConvArgs &a, hipStream_t s, long long blocks, int lds) {
-    auto k = conv_pingpong_kernel<0, MF, 0, true>;
+    auto k = conv_pingpong_kernel<0, MF, 0, true, false, HALO>;
     if (ensure_dyn_lds((const void *)k, lds) != MD_OK) return MD_ERR_HIP;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
-static int launch_conv_pingpong_head(ConvArgs &a, hipStream_t s) {
+static int launch_conv_pingpong_head(ConvArgs &a, hipStream_t s, bool halo) {
     ++g_launch_count;
     g_last_kernel = MD_CONV_KERNEL_PINGPONG;
     a.n_ctiles = 1;
     a.n_ptiles = (a.M + 255) / 256;
     a.pt_per_xcd = (a.n_ptiles + 7) / 8;
+    if (halo) pingpong_halo_tiles(a);
     const long long blocks = (long long)a.pt_per_xcd * 8;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
+    if (halo) return pingpong_wants_16x16(a) ? launch_conv_pingpong_head_mf<1, true>(a, s, blocks, HB_LDS_HEAD) : launch_conv_pingpong_head_mf<0, true>(a, s, blocks, HB_LDS_HEAD);
     const int lds = 256 * (256 * 2 + 16) + 256 * 4 + 16 * 256 * 2;  // epilogue image + bias + head weights
-    return pingpong_wants_16x16(a) ? launch_conv_pingpong_head_mf<1>(a, s, blocks, lds) : launch_conv_pingpong_head_mf<0>(a, s, blocks, lds);
+    return pingpong_wants_16x16(a) ? launch_conv_pingpong_head_mf<1, false>(a, s, blocks, lds) : launch_conv_pingpong_head_mf<0, false>(a, s, blocks, lds);
 }
 
 // the persistent form: one workgroup per CU, S = 32 / n_ctiles workgroups per (XCD, cout tile) stride through the XCD's pixel range
-template <int MF>
+template <int MF, bool HALO = false>
 static int launch_conv_pingpong_pers(ConvArgs &a, hipStream_t s) {
     ++g_launch_count;
     g_last_kernel = MD_CONV_KERNEL_PINGPONG;
     a.n_ctiles = a.Cout / 256;
     a.n_ptiles = (a.M + 255) / 256;
     a.pt_per_xcd = (a.n_ptiles + 7) / 8;
-    const int lds = 8 * 128 * ROWB + 256 * 4 + 8 * 2560;   // staging buffers + bias + eight wave-private slabs
-    auto k = a.relu == 2 ? conv_pingpong_kernel<0, MF, 2, false, true> : conv_pingpong_kernel<0, MF, 0, false, true>;
+    if (HALO) pingpong_halo_tiles(a);
+    const int lds = HALO ? HB_LDS : 8 * 128 * ROWB + 256 * 4 + 8 * 2560;   // staging buffers + bias + eight wave-private slabs (HALO: in halo buffer 1)
+    auto k = a.relu == 2 ? conv_pingpong_kernel<0, MF, 2, false, true, HALO> : conv_pingpong_kernel<0, MF, 0, false, true, HALO>;
     if (ensure_dyn_lds((const void *)k, lds) != MD_OK) return MD_ERR_HIP;
     hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
@@ -1641,6 +1792,21 @@ static int launch_conv_dual_pingpong(ConvArgs &a, hipStream_t s) {
     auto k = conv_pingpong_kernel<0, 0, 0>;
     if (ensure_dyn_lds((const void *)k, lds) != MD_OK) return MD_ERR_HIP;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
+}
+
+// plain (one tile per workgroup) HALO form: GEN 0 / 2 epilogues, optional residual with the output's layout or a channel slice
+template <int MF>
+static int launch_conv_pingpong_halo(ConvArgs &a, hipStream_t s) {
+    ++g_launch_count;
+    g_last_kernel = MD_CONV_KERNEL_PINGPONG;
+    a.n_ctiles = a.Cout / 256;
+    pingpong_halo_tiles(a);
+    const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
+    if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
+    auto k = a.relu == 2 ? conv_pingpong_kernel<0, MF, 2, false, false, true> : conv_pingpong_kernel<0, MF, 0, false, false, true>;
+    if (ensure_dyn_lds((const void *)k, HB_LDS) != MD_OK) return MD_ERR_HIP;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(512), HB_LDS, s, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
@@ -1827,7 +1993,9 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     // the 128x128 kernel); the 128-cout forms lose 2-15 % -- and every workgroup gets at least 8 tiles to stream past its weights
     const bool no_stream = variant == 31;   // 31 = the dispatcher's choice without conv1x1_stream_kernel (A/B)
     const bool no_pers = variant == 33;     // 33 = the dispatcher's choice without the persistent form of the ping-pong kernel (A/B)
-    if (no_stream || no_pers) variant = 0;
+    const bool force_halo = variant == 34;  // 34 = the dispatcher's choice, with the HALO form of the ping-pong kernel wherever it applies
+    const bool no_halo = variant == 35;     // 35 = the dispatcher's choice without the HALO form (A/B)
+    if (no_stream || no_pers || force_halo || no_halo) variant = 0;
     const bool stream_auto = variant == 0 && !no_stream && !head && dma_ok && stream1x1_takes(a) && a.Cout % 256 == 0 && a.Cin != 128 &&
                              (M + 31) / 32 * (a.Cout / (a.Cin == 512 ? 128 : 256)) >= 4096;
     if ((variant == 30 || stream_auto) && !head) {
@@ -1853,10 +2021,21 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     const double sb_part = 2.5 + 1.5 * sb_last, sb_lone = 0.0726 * (double)(a.Kpad / BK);
     const double t_sb = (double)(sb_blocks / 1024) * 4.0 + (sb_blocks % 1024 ? (sb_part > sb_lone ? sb_part : sb_lone) : 0.0);
     const bool pp_ok = fast && dma_ok && a.Cout % 256 == 0 && a.Kpad >= 1024 && pp_blocks >= 128 && t_pp <= t_sb;
+    // HALO form of the ping-pong kernel (3x3 / s1 / p1, korder-1 weights): 16 x 16-pixel tiles, the 18 x 18 halo staged once per channel
+    // chunk instead of the B tile once per tap.  Auto where the 2-D tiles cover the image with little waste and the layer is long enough
+    // for the energy per K tile to matter (r03 tools/pp_halo_ab.py)
+    const long long halo_tiles = (long long)a.N * pingpong_halo_tiles_per_image(a.H, a.W, nullptr, nullptr);
+    const bool halo_plain_out = !a.adv || (a.os == 1 && a.oy == 0 && a.ox == 0 && a.Ho == a.Hf && a.Wo == a.Wf);
+    const bool halo_ok_pp = fast && dma_ok && pingpong_halo_takes(a) && halo_plain_out && a.Cout % 256 == 0;
+    // r03 tools/pp_halo_ab.py (batch 60, same box, interleaved, bit-identical): the fused-head form gains 6.3 % on 200x336 (0.2 % idle tile
+    // pixels) and 3.2 % on 100x168 (9 % idle), loses 13 % on 50x84 (22 % idle); the one-tile form gains 4 % on 200x336 but stays behind the
+    // persistent linear-tile form (which the persistent HALO form only equals) -> auto for the head form where the tiles fit
+    const bool halo_auto = halo_ok_pp && !no_halo && head != nullptr && (double)M >= 0.90 * (double)(halo_tiles * 256);
+    const bool halo_pp = halo_ok_pp && (force_halo || halo_auto);
     if (head) {
         if (!(fast && dma_ok && a.Cout == 256 && !a.adv && !a.res && a.relu == 1 && pp_blocks >= 64)) return MD_ERR_UNSUPPORTED_INTERNAL;
         a.w2 = head->w2; a.b2 = head->b2; a.y2 = head->y2;
-        return launch_conv_pingpong_head(a, s);
+        return launch_conv_pingpong_head(a, s, halo_pp);
     }
     // 3x3 layers on <= 256 channels: the 64-cout halo-reuse kernel at four workgroups per CU beats the 128x128 kernel wherever
     // the ping-pong kernel does not apply, and beats the ping-pong kernel when its 256x256 tiles fill the last of several rounds
@@ -1884,9 +2063,14 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
         const bool cat_only_p = !a.adv || (a.os == 1 && a.oy == 0 && a.ox == 0 && a.Ho == a.Hf && a.Wo == a.Wf);
         const bool pers_ok = fast && dma_ok && a.Cout % 256 == 0 && !a.res && !a.res_up && cat_only_p && 32 % (a.Cout / 256) == 0 && pp_blocks > 256;
         const bool pers_auto = variant == 0 && !no_pers && pp_ok && pers_ok && a.Kpad >= tn.pers_min_k;
-        if ((variant == 32 || pers_auto) && pers_ok) return pingpong_wants_16x16(a) ? launch_conv_pingpong_pers<1>(a, s) : launch_conv_pingpong_pers<0>(a, s);
+        if ((variant == 32 || pers_auto) && pers_ok) {
+            // (persistent + HALO exists on the 16x16x32 MFMA shape only: the 32x32x16 instantiation needs 258 registers)
+            if (halo_pp && 32 % (a.Cout / 256) == 0 && halo_tiles * (a.Cout / 256) > 256) return launch_conv_pingpong_pers<1, true>(a, s);
+            return pingpong_wants_16x16(a) ? launch_conv_pingpong_pers<1>(a, s) : launch_conv_pingpong_pers<0>(a, s);
+        }
         if (variant == 32) variant = 0;
     }
+    if (variant == 0 && pp_ok && halo_pp) return pingpong_wants_16x16(a) ? launch_conv_pingpong_halo<1>(a, s) : launch_conv_pingpong_halo<0>(a, s);
     if (variant == 0 && pp_ok) return pingpong_wants_16x16(a) ? launch_conv_pingpong<0, 1>(a, s) : launch_conv_pingpong<0>(a, s);
     if (halo_ok && !a.res_up && variant == 11) return launch_conv3x3_halo<128, false>(a, s);  // superseded by the paths around it
     // 64-cout tiles of the halo kernel at four workgroups per CU (variant 27; auto for Cout <= 64)
@@ -1897,6 +2081,15 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
                            a.Cin % 64 == 0 && a.Cout % 64 == 0 && cout_pad % 64 == 0 && !a.res_up && a.Ho == a.H && a.Wo == a.W;
     if (halo64_ok && (variant == 27 || (variant == 0 && ctile == 64))) return launch_conv3x3_halo<64, true>(a, s);
     if (variant == 11) variant = 2;
+    // 36 / 37: the HALO form pinned (32x32x16 / 16x16x32 MFMA), 38: its persistent form; where it does not apply: the plain ping-pong kernel
+    if ((variant == 36 || variant == 37 || variant == 38) && fast && dma_ok && a.Cout % 256 == 0) {
+        const bool gen_plain = (!a.adv || halo_plain_out) && !a.res_up;
+        if (halo_ok_pp && gen_plain) {
+            if (variant == 38 && !a.res && 32 % (a.Cout / 256) == 0 && halo_tiles * (a.Cout / 256) > 256) return launch_conv_pingpong_pers<1, true>(a, s);
+            return variant == 36 ? launch_conv_pingpong_halo<0>(a, s) : launch_conv_pingpong_halo<1>(a, s);
+        }
+        return variant == 36 ? launch_conv_pingpong<0>(a, s) : launch_conv_pingpong<0, 1>(a, s);
+    }
     if (variant == 15 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0>(a, s);  // 256x256 ping-pong, 8 waves
     if (variant == 22 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0, 1>(a, s);  // same, 16x16x32 MFMA
 #ifdef MD_DIAG

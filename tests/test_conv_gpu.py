@@ -682,3 +682,87 @@ def test_conv1x1_dual_on_the_pingpong_kernel(cfg):
     assert lib.md_conv2d_last_kernel() == 1, "the long-K dual GEMM did not reach the ping-pong kernel"
     torch.cuda.synchronize()
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("cfg", [
+    # name, N, H, W, Cin, Cout, act, residual, concat output, channel-slice input
+    ("ragged_128_256_relu", 3, 37, 53, 128, 256, "relu", False, False, False),
+    ("exact_tiles_256_512_res", 2, 32, 48, 256, 512, "relu", True, False, False),
+    ("odd_chunks_192_256_silu_res_cat", 2, 41, 19, 192, 256, "silu", True, True, False),
+    ("one_row_of_tiles_256_256_slice_in", 1, 9, 130, 256, 256, "none", False, False, True),
+    ("only_the_8x32_strip_128_256", 2, 8, 70, 128, 256, "relu", True, False, False),
+    ("tiles_and_strip_256_256", 2, 40, 100, 256, 256, "relu", False, False, False),
+])
+def test_pingpong_halo_form_is_bit_identical(cfg):
+    """The HALO form of the ping-pong kernel (16 x 16-pixel tiles, the 18 x 18 halo staged once per channel chunk, B fragments read out of it
+    with shifted rows; variants 36 / 37 = 32x32x16 / 16x16x32 MFMA) == the linear-tile ping-pong kernel (variants 15 / 22) bit for bit:
+    same K order, same MFMA sequence per output element.  Ragged tiles at the right / bottom image edges, an odd number of channel chunks,
+    residual, SiLU, concat output, channel-slice input; and fp32 torch as the independent check."""
+    from minddet_amd import _lib, nn_ops
+
+    name, N, H, W, Cin, Cout, act, with_res, cat, slice_in = cfg
+    g = torch.Generator().manual_seed(len(name) + H)
+    wt = torch.randn((Cout, Cin, 3, 3), generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    pc = nn_ops.pack_conv(wt, bias=bias, stride=1, pad=1, relu={"relu": 1, "silu": "silu", "none": 0}[act]).to(DEV)
+    assert pc.korder == 1
+    xs = 2 * Cin if slice_in else Cin
+    xw = torch.randn((N, H, W, xs), generator=g).to(torch.bfloat16).to(DEV)
+    x_c_off = Cin if slice_in else None
+    r = torch.randn((N, H, W, Cout), generator=g).to(torch.bfloat16).to(DEV) if with_res else None
+    # (a concat output takes its residual as a channel slice of a wider tensor)
+    r_wide = torch.cat([torch.zeros_like(r), r], -1).contiguous() if (with_res and cat) else None
+
+    def run(v):
+        out = torch.zeros((N, H, W, 2 * Cout), dtype=torch.bfloat16, device=DEV) if cat else None
+        y = nn_ops.conv2d(xw, pc, residual=r_wide if r_wide is not None else r, variant=v, out=out, c_off=Cout if cat else 0, x_c_off=x_c_off,
+                          res_c_off=Cout if r_wide is not None else None)
+        assert _lib.lib().md_conv2d_last_kernel() == 1
+        return y
+
+    ref0, ref1 = run(15), run(22)
+    h0, h1 = run(36), run(37)
+    torch.cuda.synchronize()
+    assert torch.equal(ref0, ref1) and torch.equal(h0, ref0) and torch.equal(h1, ref0), name
+    if cat:
+        assert float(h0[..., :Cout].abs().sum()) == 0
+    x = xw[..., Cin:] if slice_in else xw
+    c = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wt.to(torch.bfloat16).float(), bias, padding=1)
+    if act == "silu":
+        c = (c * torch.sigmoid(c)).to(torch.bfloat16).float()
+        if with_res:
+            c = c + r.float().cpu().permute(0, 3, 1, 2)
+    else:
+        if with_res:
+            c = c.to(torch.bfloat16).float() + r.float().cpu().permute(0, 3, 1, 2)
+        if act == "relu":
+            c = torch.relu(c)
+    ref = c.permute(0, 2, 3, 1)
+    got = (h0[..., Cout:] if cat else h0).float().cpu()
+    rms = ref.pow(2).mean().sqrt().item()
+    assert ((got - ref).abs() <= 1.5e-2 * ref.abs() + 1.5e-2 * rms).all(), name
+
+
+def test_pingpong_halo_persistent_and_head_forms_are_bit_identical():
+    """The persistent HALO form (variant 38: several 16 x 16 tiles per workgroup, slabs in the idle halo buffer, per-pixel range-checked
+    stores) == the persistent linear-tile form (32); md_conv2d_head on the HALO form (variant 34) == without it (35); ragged image edges."""
+    from minddet_amd import _lib, nn_ops
+
+    g = torch.Generator().manual_seed(77)
+    for (N, H, W, Cin, Cout, act) in ((6, 100, 168, 256, 256, "relu"), (5, 90, 75, 128, 512, "silu")):
+        wt = torch.randn((Cout, Cin, 3, 3), generator=g) * (2.0 / (9 * Cin)) ** 0.5
+        pc = nn_ops.pack_conv(wt, bias=torch.randn((Cout,), generator=g) * 0.1, stride=1, pad=1, relu=1 if act == "relu" else "silu").to(DEV)
+        x = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16).to(DEV)
+        ref = nn_ops.conv2d(x, pc, variant=32)
+        got = nn_ops.conv2d(x, pc, variant=38)
+        assert _lib.lib().md_conv2d_last_kernel() == 1
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref) and torch.equal(ref, nn_ops.conv2d(x, pc, variant=22)), (N, H, W)
+    for (n, h, w) in ((2, 96, 96), (3, 75, 91), (1, 200, 336)):
+        w1 = torch.randn((256, 256, 3, 3), generator=g) * (2.0 / 2304) ** 0.5
+        pc = nn_ops.pack_conv(w1, bias=torch.randn((256,), generator=g) * 0.1, stride=1, pad=1, relu=True).to(DEV)
+        pc2 = nn_ops.pack_conv(torch.randn((15, 256, 1, 1), generator=g) * 0.05, bias=torch.randn((15,), generator=g) * 0.1).to(DEV)
+        x = torch.randn((n, h, w, 256), generator=g).to(torch.bfloat16).to(DEV)
+        a_, b_ = nn_ops.conv2d_head(x, pc, pc2, variant=35), nn_ops.conv2d_head(x, pc, pc2, variant=34)
+        torch.cuda.synchronize()
+        assert torch.equal(a_, b_), (n, h, w)
