@@ -1510,6 +1510,10 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         const int e_px = lane >> 3, e_ch = lane & 7;
         const int v_io = ((wc * 64 + e_px) * a.Ctot + wr * 128 + e_ch * 8) * 2, row_b = a.Ctot * 2;
         auto flush_slab = [&](int px0, int c0) {   // pixels px0 .. px0 + 15 of the wave's 64, couts c0 .. c0 + 63 of its 128
+            // compiler-level ordering points on both sides of the read-out: the slab is written by some lanes and read back by others in
+            // another vector type, and hipcc may otherwise move (or duplicate into the non-writing lanes) the reads across the writes --
+            // seen in bottleneck64_kernel's slab epilogue (r03).  LDS operations of one wave execute in issue order: no hardware wait.
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(slab + (e_px + 8 * it) * 144 + e_ch * 16);
@@ -1522,6 +1526,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
                 } else
                 __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, v_io + (px0 + 8 * it) * row_b, c0 * 2, 2);
             }
+            asm volatile("" ::: "memory");
         };
         if constexpr (MF == 0) {
 #pragma unroll
@@ -1995,7 +2000,9 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     const bool no_pers = variant == 33;     // 33 = the dispatcher's choice without the persistent form of the ping-pong kernel (A/B)
     const bool force_halo = variant == 34;  // 34 = the dispatcher's choice, with the HALO form of the ping-pong kernel wherever it applies
     const bool no_halo = variant == 35;     // 35 = the dispatcher's choice without the HALO form (A/B)
-    if (no_stream || no_pers || force_halo || no_halo) variant = 0;
+    const bool halo_fit = variant == 39;    // 39 = auto, with the HALO form also for the persistent / one-tile forms where the tiles fit the image (A/B)
+    const bool halo_not_pers = variant == 40;   // 40 = auto, but layers the persistent form would take run on the one-tile HALO form where the tiles fit (A/B)
+    if (no_stream || no_pers || force_halo || no_halo || halo_fit || halo_not_pers) variant = 0;
     const bool stream_auto = variant == 0 && !no_stream && !head && dma_ok && stream1x1_takes(a) && a.Cout % 256 == 0 && a.Cin != 128 &&
                              (M + 31) / 32 * (a.Cout / (a.Cin == 512 ? 128 : 256)) >= 4096;
     if ((variant == 30 || stream_auto) && !head) {
@@ -2031,7 +2038,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     // pixels) and 3.2 % on 100x168 (9 % idle), loses 13 % on 50x84 (22 % idle); the one-tile form gains 4 % on 200x336 but stays behind the
     // persistent linear-tile form (which the persistent HALO form only equals) -> auto for the head form where the tiles fit
     const bool halo_auto = halo_ok_pp && !no_halo && head != nullptr && (double)M >= 0.90 * (double)(halo_tiles * 256);
-    const bool halo_pp = halo_ok_pp && (force_halo || halo_auto);
+    const bool halo_pp = halo_ok_pp && (force_halo || halo_auto || (halo_fit && (double)M >= 0.99 * (double)(halo_tiles * 256)));
     if (head) {
         if (!(fast && dma_ok && a.Cout == 256 && !a.adv && !a.res && a.relu == 1 && pp_blocks >= 64)) return MD_ERR_UNSUPPORTED_INTERNAL;
         a.w2 = head->w2; a.b2 = head->b2; a.y2 = head->y2;
@@ -2062,7 +2069,8 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     {
         const bool cat_only_p = !a.adv || (a.os == 1 && a.oy == 0 && a.ox == 0 && a.Ho == a.Hf && a.Wo == a.Wf);
         const bool pers_ok = fast && dma_ok && a.Cout % 256 == 0 && !a.res && !a.res_up && cat_only_p && 32 % (a.Cout / 256) == 0 && pp_blocks > 256;
-        const bool pers_auto = variant == 0 && !no_pers && pp_ok && pers_ok && a.Kpad >= tn.pers_min_k;
+        const bool pers_auto = variant == 0 && !no_pers && pp_ok && pers_ok && a.Kpad >= tn.pers_min_k &&
+                               !(halo_not_pers && halo_ok_pp && (double)M >= 0.99 * (double)(halo_tiles * 256));
         if ((variant == 32 || pers_auto) && pers_ok) {
             // (persistent + HALO exists on the 16x16x32 MFMA shape only: the 32x32x16 instantiation needs 258 registers)
             if (halo_pp && 32 % (a.Cout / 256) == 0 && halo_tiles * (a.Cout / 256) > 256) return launch_conv_pingpong_pers<1, true>(a, s);
@@ -2070,7 +2078,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
         }
         if (variant == 32) variant = 0;
     }
-    if (variant == 0 && pp_ok && halo_pp) return pingpong_wants_16x16(a) ? launch_conv_pingpong_halo<1>(a, s) : launch_conv_pingpong_halo<0>(a, s);
+    if (variant == 0 && pp_ok && (halo_pp || (halo_not_pers && halo_ok_pp && (double)M >= 0.99 * (double)(halo_tiles * 256)))) return pingpong_wants_16x16(a) ? launch_conv_pingpong_halo<1>(a, s) : launch_conv_pingpong_halo<0>(a, s);
     if (variant == 0 && pp_ok) return pingpong_wants_16x16(a) ? launch_conv_pingpong<0, 1>(a, s) : launch_conv_pingpong<0>(a, s);
     if (halo_ok && !a.res_up && variant == 11) return launch_conv3x3_halo<128, false>(a, s);  // superseded by the paths around it
     // 64-cout tiles of the halo kernel at four workgroups per CU (variant 27; auto for Cout <= 64)
