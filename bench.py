@@ -63,6 +63,8 @@ def parse_args(argv=None):
     ap.add_argument("--spawn", action="store_true",
                     help="start the --gpus ranks from this process even for N = 1 (the RCCL path with one rank)")
     ap.add_argument("--no-from-uint8", action="store_true", help="skip the extra from-uint8 pass (from_uint8 in the line)")
+    ap.add_argument("--paste-masks", action="store_true",
+                    help="Mask R-CNN configs: paste the 28x28 masks into the image inside the step (md_paste_masks -> [B,max_det,H,W/32] bit masks)")
     ap.add_argument("--no-zero-operands", action="store_true",
                     help="skip the zero-operand replay of the dominant kernel (roofline.zero_operands)")
     return ap.parse_args(argv)
@@ -310,6 +312,8 @@ def main(argv=None):
         args.config = os.path.join(ROOT, args.config)   # a repo-relative path from another working directory (rocprofv3 runs from /tmp)
     cfg = Config.fromfile(args.config)
     model = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(dev)
+    if args.paste_masks and hasattr(model, "paste"):
+        model.paste = True
     H, W = cfg.data.input_hw
     B = args.batch
     images = synthetic_images(B, H, W, seed=20240317 + rank, device=dev)
@@ -625,6 +629,25 @@ def main(argv=None):
         with open(args.dump_convs, "w") as f:
             json.dump(rows, f, indent=1)
 
+    # Mask R-CNN: the pasting launch on its own (HBM-write-bound: H * W / 8 bytes per detection slot), from the last step's outputs
+    mask_paste = None
+    if rank == 0 and hasattr(model, "mask_head") and not args.graph:
+        from minddet_amd import det_ops
+
+        out_m = model.forward(images, paste=False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        det_ops.paste_masks(out_m[2], out_m[0], (H, W), model.mask_thr, bits=True)
+        e0.record()
+        for _ in range(5):
+            pm = det_ops.paste_masks(out_m[2], out_m[0], (H, W), model.mask_thr, bits=True)
+        e1.record()
+        torch.cuda.synchronize()
+        t_p = e0.elapsed_time(e1) / 5 * 1e-3
+        mask_paste = {"in_step": bool(model.paste), "ms": round(t_p * 1e3, 4), "bytes_written": int(pm.numel() * 4),
+                      "gb_per_s": round(pm.numel() * 4 / t_p / 1e9, 1), "frac_of_hbm_peak": round(pm.numel() * 4 / t_p / PEAK_HBM_BPS, 4),
+                      "what": "md_paste_masks: [B,max_det,28,28] probabilities -> [B,max_det,H,W/32] int32 bit masks at mask_thr_binary"}
+        del pm, out_m
+
     is_frcnn = type(model).__name__ == "FasterRCNN"
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and is_frcnn:
@@ -668,7 +691,7 @@ def main(argv=None):
             "config": {"workload": wl, "batch_per_gpu": B,
                        "global_batch": world * B, "parallelism": f"dp{world} (image sharding + all_gather of detections)",
                        "gmac_per_image": None if gmac is None else round(gmac, 2), "weights": "random init, seed 7"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "from_uint8": from_u8,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "from_uint8": from_u8, "mask_paste": mask_paste,
             # images (over every step of this run) whose class-wise NMS saw a FULL top-nms_pre prefix and fewer than max_det
             # survivors: only those can differ from the NMS over every candidate (DESIGN.md "pre-NMS prefix"); read after timing
             "nms_prefix": None if not hasattr(model, "prefix_status") else {

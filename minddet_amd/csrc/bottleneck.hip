@@ -29,6 +29,7 @@
 // the fragment reads (conflict-free ds_read_b128), as in conv.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "aot.h"
 
@@ -497,7 +498,12 @@ extern "C" int md_bottleneck(MD_AOT_ARGS) {
     const long long per = lim / x_img < N ? lim / x_img : N;
     const int tiles_x = (int)((W + BN_TW - 1) / BN_TW), tiles_y = (int)((H + BN_TH - 1) / BN_TH);
     auto k = params[7] ? bottleneck64_kernel<2> : (params[6] ? bottleneck64_kernel<1> : bottleneck64_kernel<0>);
-    if (ensure_dyn_lds((const void *)k, BN_LDS) != MD_OK) return MD_ERR_HIP;
+    int bn_lds = BN_LDS;
+#ifdef MD_DIAG
+    // occupancy experiment (tools only): MD_BN_LDS > 80 KiB leaves room for ONE workgroup per CU instead of two
+    if (const char *e = getenv("MD_BN_LDS")) bn_lds = atoi(e) > BN_LDS ? atoi(e) : BN_LDS;
+#endif
+    if (ensure_dyn_lds((const void *)k, bn_lds) != MD_OK) return MD_ERR_HIP;
     for (long long n0 = 0; n0 < N; n0 += per) {
         const long long nn = N - n0 < per ? N - n0 : per;
         BottleneckArgs a;
@@ -520,7 +526,7 @@ extern "C" int md_bottleneck(MD_AOT_ARGS) {
 #ifdef MD_DIAG
         a.dbg = g_bn_stamp_buf;
 #endif
-        hipLaunchKernelGGL(k, dim3((unsigned)(a.pt_per_xcd * 8)), dim3(512), BN_LDS, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(k, dim3((unsigned)(a.pt_per_xcd * 8)), dim3(512), bn_lds, (hipStream_t)stream, a);
         md_note_conv_kernel(MD_CONV_KERNEL_BOTTLENECK);
     }
     MD_HIP_TRY(hipGetLastError());

@@ -1928,7 +1928,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     // DMA -> MFMA loop beat 2 double-buffered ones on every benchmark layer (+8...43 %); variant 2 keeps the double buffer
     a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 25 || at->variant == 30 || at->variant == 31 || at->variant == 32 || at->variant == 33;
     a.stamp = 0; a.dbg = nullptr;
-    if ((at->variant >= 17 && at->variant <= 19) || at->variant == 25) {
+    if ((at->variant >= 17 && at->variant <= 19) || at->variant == 25 || at->variant == 26) {
         // timing ablations / stamp builds: wrong results by construction, so not part of the product library
         if (!kDiag) return MD_ERR_ARG;
 #ifdef MD_DIAG
@@ -2101,6 +2101,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     if (variant == 15 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0>(a, s);  // 256x256 ping-pong, 8 waves
     if (variant == 22 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0, 1>(a, s);  // same, 16x16x32 MFMA
 #ifdef MD_DIAG
+    if (variant == 26 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<4, 1>(a, s);   // stamps, 16x16x32 MFMA
     if (variant >= 17 && variant <= 19 && fast && dma_ok && a.Cout % 256 == 0)                       // timing ablations
         return variant == 17 ? launch_conv_pingpong<1>(a, s) : (variant == 18 ? launch_conv_pingpong<2>(a, s) : launch_conv_pingpong<4>(a, s));
 #endif
