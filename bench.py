@@ -481,6 +481,14 @@ def main(argv=None):
     instrument_off()
     survey = survey or None
     host_enqueue_ms = None if HOST_ENQUEUE["s"] is None else HOST_ENQUEUE["s"] / max(args.steps, 1) * 1e3
+    # ... and of ONE step enqueued into an empty queue (device idle before, no synchronisation until the host is done): the pure cost of
+    # Python + ctypes + launches, free of any back-pressure of a full queue that the in-run figure may contain
+    torch.cuda.synchronize()
+    t_h0 = time.perf_counter()
+    step()
+    host_single_ms = (time.perf_counter() - t_h0) * 1e3
+    finish()
+    torch.cuda.synchronize()
 
     # the end-to-end figure from a resident uint8 batch (md_image_preprocess inside the step), next to the resident-layout one
     from_u8 = None
@@ -686,6 +694,7 @@ def main(argv=None):
             # host time per step spent ENQUEUING (Python + ctypes + launches) in the timed region, before the closing device sync: well
             # under ms_per_step = the device is the bottleneck and N Python ranks on one node are not launch-bound
             "host_enqueue_ms_per_step": None if host_enqueue_ms is None else round(host_enqueue_ms, 3),
+            "host_enqueue_ms_single_step": round(host_single_ms, 3),
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B,

@@ -1192,8 +1192,22 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         t_n = pt / per;
         const int rr = pt - t_n * per;
         if (rr < full) {
-            const int ty = rr / a.tiles_x;
-            t_y0 = ty * 16; t_x0 = (rr - ty * a.tiles_x) * 16;
+            // 16 x 16 tiles in BLOCKED order: bands of 4 tile rows, inside a band blocks of 8 tile columns, row-major inside a block.  The
+            // 32 workgroups an XCD runs at a time then cover a compact 128 x 64-pixel region instead of one and a half tile rows, so most
+            // halo rows / columns a tile shares with its neighbours are fetched while a neighbour holds them in the XCD's L2 (r03 PMC:
+            // the row-major order re-fetched 1.29 x the algorithmic bytes from beyond L2)
+            const int band_sz = a.tiles_x * 4, band = rr / band_sz, q = rr - band * band_sz;
+            const int hb = a.tiles_y - band * 4 < 4 ? a.tiles_y - band * 4 : 4;   // tile rows of this band
+            const int nfull = (a.tiles_x >> 3) * 8 * hb;                            // tiles of the band inside whole 8-column blocks
+            int ty, tx;
+            if (q < nfull) {
+                const int blk = q / (8 * hb), o = q - blk * 8 * hb;
+                ty = o >> 3; tx = blk * 8 + (o & 7);
+            } else {
+                const int remx = a.tiles_x & 7, o = q - nfull;
+                ty = o / remx; tx = (a.tiles_x & ~7) + o - ty * remx;
+            }
+            t_y0 = (band * 4 + ty) * 16; t_x0 = tx * 16;
             t_twl = 4; t_hw = 18; t_magic = 3641; t_hpix = 324;
         } else {   // the bottom strip: 8 x 32 tiles
             t_y0 = a.tiles_y * 16; t_x0 = (rr - full) * 32;

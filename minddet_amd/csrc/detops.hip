@@ -676,6 +676,61 @@ __global__ __launch_bounds__(256) void roi_align_c32_kernel(RoiArgs a, const flo
         // the thread's four 16-B chunks are cv chunks apart (chunks c32, c32 + cv, ...): a load instruction of the cv threads of a
         // bin then covers one contiguous cv*16-B run of the pixel (whole 128-B lines for C = 256) instead of every fourth chunk
         const uint16_t *base = L.feat + (size_t)b * L.H * L.W * a.C + c32 * 8;
+        if (g == 2) {
+            // sampling_ratio 2 (the detectors' setting): the 2 x 2 samples of a bin form a grid, so the weight of pixel (r, c) is
+            // (sum over sample rows of the row's weight at r) x (the same over sample columns at c), and neighbouring samples share rows /
+            // columns whenever the bin is under 2 pixels wide: the up to 4 rows and 4 columns are DEDUPLICATED and each distinct pixel is
+            // loaded once -- 4 to 16 pixel loads per bin instead of always 16 (r03: the kernel is bound by the bytes through the CU's
+            // vector L1, 16 taps x 512 B per bin; typical RoIs at their FPN level have 1-4-pixel bins).  fp32 sums in another order than the
+            // tap-by-tap form: same bf16 tolerance.
+            int ri[4], ci[4];
+            float wy[4], wx[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float y = y1 + (float)ph * bh + ((float)i + 0.5f) * bh * 0.5f;
+                const float x = x1 + (float)pw * bw + ((float)i + 0.5f) * bw * 0.5f;
+                const bool oky = !(y < -1.0f || y > (float)L.H), okx = !(x < -1.0f || x > (float)L.W);
+                float yy = fmaxf(y, 0.f), xx = fmaxf(x, 0.f);
+                int y_lo = (int)yy, x_lo = (int)xx, y_hi, x_hi;
+                if (y_lo >= L.H - 1) { y_hi = y_lo = L.H - 1; yy = (float)y_lo; } else y_hi = y_lo + 1;
+                if (x_lo >= L.W - 1) { x_hi = x_lo = L.W - 1; xx = (float)x_lo; } else x_hi = x_lo + 1;
+                const float ly = yy - (float)y_lo, lx = xx - (float)x_lo;
+                ri[2 * i] = y_lo; ri[2 * i + 1] = y_hi; wy[2 * i] = oky ? 1.f - ly : 0.f; wy[2 * i + 1] = oky ? ly : 0.f;
+                ci[2 * i] = x_lo; ci[2 * i + 1] = x_hi; wx[2 * i] = okx ? 1.f - lx : 0.f; wx[2 * i + 1] = okx ? lx : 0.f;
+            }
+            // merge equal indices into the earliest slot (the later slot's weight becomes 0 and its pixel is never loaded)
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < j; ++k) {
+                    if (ri[j] == ri[k] && wy[j] != 0.f) { wy[k] += wy[j]; wy[j] = 0.f; }
+                    if (ci[j] == ci[k] && wx[j] != 0.f) { wx[k] += wx[j]; wx[j] = 0.f; }
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (wy[i] == 0.f) continue;
+                const uint16_t *rowp = base + (size_t)ri[i] * L.W * a.C;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float w = wy[i] * wx[j];
+                    if (w == 0.f) continue;
+                    const uint4 *pp = reinterpret_cast<const uint4 *>(rowp + (size_t)ci[j] * a.C);
+                    uint4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = pp[q * cv];
+                    const f32x2 w2 = (f32x2){w, w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned wd[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const f32x2 pr = (f32x2){__uint_as_float(wd[d] << 16), __uint_as_float(wd[d] & 0xffff0000u)};
+                            acc[q * 4 + d] = __builtin_elementwise_fma(w2, pr, acc[q * 4 + d]);
+                        }
+                    }
+                }
+            }
+        } else
         for (int iy = 0; iy < g; ++iy) {
             const float y = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)g;
             for (int ix = 0; ix < g; ++ix) {

@@ -388,11 +388,12 @@ struct PasteArgs {
 template <bool BITS>
 __global__ __launch_bounds__(256) void paste_masks_kernel(PasteArgs a) {
     constexpr int PX = BITS ? 32 : 4;
-    const size_t total = (size_t)a.R * a.H * a.Ww;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int wx = (int)(e % a.Ww);
-        const size_t t = e / a.Ww;
-        const int py = (int)(t % a.H), r = (int)(t / a.H);
+    // 32-bit index arithmetic (the host checks R * H * Ww < 2^32): 64-bit divisions were the larger part of this write-bound kernel's time
+    const unsigned total = (unsigned)a.R * (unsigned)a.H * (unsigned)a.Ww;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned t = e / (unsigned)a.Ww;
+        const int wx = (int)(e - t * (unsigned)a.Ww);
+        const int r = (int)(t / (unsigned)a.H), py = (int)(t - (unsigned)r * (unsigned)a.H);
         const float *d = a.dets + (size_t)r * 6;
         const float x0 = d[0], y0 = d[1], bw = __fsub_rn(d[2], d[0]), bh = __fsub_rn(d[3], d[1]);
         unsigned word = 0u;
@@ -454,10 +455,10 @@ extern "C" int md_paste_masks(MD_AOT_ARGS) {
     if (shapes[2][0] != R || shapes[2][1] != H || shapes[2][2] != (at->bits ? Ww : W)) return MD_ERR_ARG;
     if (R == 0) return MD_OK;
     if (!params[0] || !params[1] || !params[2]) return MD_ERR_ARG;
-    if (R > 0x7fffffffLL / 6) return MD_ERR_SIZE;
+    if (R > 0x7fffffffLL / 6 || (long long)R * H * Ww >= 0xffffffffLL) return MD_ERR_SIZE;
     md::PasteArgs a = {(const float *)params[0], (const float *)params[1], params[2], (int)R, (int)S, (int)H, (int)W, (int)Ww, at->threshold};
     const size_t total = (size_t)R * H * Ww, nb = (total + 255) / 256;
-    const unsigned grid = (unsigned)(nb < 65535u * 64 ? nb : 65535u * 64);
+    const unsigned grid = (unsigned)(nb < 256u * 64 ? nb : 256u * 64);   // grid-stride: 64 blocks per CU
     if (at->bits) hipLaunchKernelGGL(md::paste_masks_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(md::paste_masks_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
