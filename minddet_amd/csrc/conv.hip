@@ -138,10 +138,10 @@ static thread_local long long g_launch_count = 0;
 // Per-call tuning (md_conv_tune of the op's attribute struct, resolved against the defaults): the library keeps no mutable knob.
 struct Tune {
     long long chunk_limit;   // activation bytes above which the batch is sliced into image chunks (the kernels' 32-bit DMA offsets)
-    int stream_rounds, stream_wgs_per_cu, stream_cache_bits, pers_min_k, dual_pp_min_k;
+    int stream_rounds, stream_wgs_per_cu, stream_cache_bits, pers_min_k, dual_pp_min_k, pp_cache_bits;
 };
 static Tune resolve_tune(const md_conv_tune *t) {
-    Tune r = {0x7fff0000LL, 1, 2, 6, 2304, 768};
+    Tune r = {0x7fff0000LL, 1, 2, 6, 2304, 768, 0};
     if (!t) return r;
     if (t->chunk_limit > 0 && t->chunk_limit < 0x7fff0000) r.chunk_limit = t->chunk_limit;
     if (t->stream_rounds >= 1 && t->stream_rounds <= 64) r.stream_rounds = t->stream_rounds;
@@ -149,6 +149,7 @@ static Tune resolve_tune(const md_conv_tune *t) {
     if (t->stream_cache_bits & 8) r.stream_cache_bits = t->stream_cache_bits & 7;
     if (t->pers_min_k >= 1) r.pers_min_k = t->pers_min_k;
     if (t->dual_pp_min_k >= 128) r.dual_pp_min_k = t->dual_pp_min_k;
+    if (t->pp_cache_bits & 8) r.pp_cache_bits = t->pp_cache_bits & 7;
     return r;
 }
 
@@ -1285,7 +1286,10 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const unsigned voff = ((p_taps[hB * 2 + i] >> (w.tap & 31)) & 1u) ? ((unsigned)(p_base[hB * 2 + i] + soff) | dead) : OOR;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(dst + i * 64 * ROWB), 16, (int)voff, 0, 0, 0);
+            // a.tune bit 0: the activation stream is requested non-temporal (it should not push the weights, which every workgroup of the XCD
+            // re-reads per K tile, out of the XCD's L2)
+            if (a.tune & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(dst + i * 64 * ROWB), 16, (int)voff, 0, 0, 2);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(dst + i * 64 * ROWB), 16, (int)voff, 0, 0, 0);
         }
     };
 
@@ -1297,7 +1301,12 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
             const bool real = j < 6 && piece < HB_ROWS / 8 && c < nch;
             const unsigned off = piece_off(j < 6 ? j : 5, c);
             char *dst = smem + (real ? HB0_OFF + (c & 1) * HB_BYTES + piece * 1024 : HB_DUMMY);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)dst, 16, (int)(real ? off : OOR), (c < nch ? c : 0) * (BK * 2), 0, 0);
+            // The halo is requested NON-TEMPORAL: every line is read once per tile (its neighbours' reads of the shared halo columns come within
+            // microseconds), so it need not push the weights -- re-read by every workgroup of the XCD per K tile -- out of the XCD's L2.
+            // r03 PMC (60 x 200 x 336, head form): L2-miss traffic 2.43 -> 2.27 GB per launch = 1.11 x the algorithmic bytes (1.28 x on linear
+            // tiles, whose nine reads per line need the L2 and get 4.3 x the traffic under nt).  a.tune bit 1 switches it off (A/B).
+            if (!(a.tune & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)dst, 16, (int)(real ? off : OOR), (c < nch ? c : 0) * (BK * 2), 0, 2);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)dst, 16, (int)(real ? off : OOR), (c < nch ? c : 0) * (BK * 2), 0, 0);
         }
     };
 
@@ -1941,6 +1950,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     // one LDS staging buffer by default: measured r01 (tools/conv_ab.py), 4 resident workgroups per CU with a serial
     // DMA -> MFMA loop beat 2 double-buffered ones on every benchmark layer (+8...43 %); variant 2 keeps the double buffer
     a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 25 || at->variant == 30 || at->variant == 31 || at->variant == 32 || at->variant == 33;
+    a.tune = tn.pp_cache_bits;   // ping-pong kernel cache policy (conv1x1_stream_kernel sets its own in its launcher)
     a.stamp = 0; a.dbg = nullptr;
     if ((at->variant >= 17 && at->variant <= 19) || at->variant == 25 || at->variant == 26) {
         // timing ablations / stamp builds: wrong results by construction, so not part of the product library
