@@ -142,8 +142,6 @@ typedef struct md_conv_tune {
                                   K >= this; 0 = default 2304 */
     int32_t dual_pp_min_k;     /* md_conv1x1_dual runs on the ping-pong kernel when its concatenated K is >= this (and Cout % 256 == 0,
                                   no residual tensor); 0 = default 768 */
-    int32_t pp_cache_bits;     /* conv_pingpong_kernel cache policy: 0 = default; else 8 | bits (1 = linear-tile forms: activation DMA
-                                  non-temporal [default off]; 2 = HALO form: halo DMA NOT non-temporal [default: non-temporal]) */
 } md_conv_tune;
 
 typedef struct md_conv2d_attrs {

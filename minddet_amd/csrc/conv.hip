@@ -138,10 +138,10 @@ static thread_local long long g_launch_count = 0;
 // Per-call tuning (md_conv_tune of the op's attribute struct, resolved against the defaults): the library keeps no mutable knob.
 struct Tune {
     long long chunk_limit;   // activation bytes above which the batch is sliced into image chunks (the kernels' 32-bit DMA offsets)
-    int stream_rounds, stream_wgs_per_cu, stream_cache_bits, pers_min_k, dual_pp_min_k, pp_cache_bits;
+    int stream_rounds, stream_wgs_per_cu, stream_cache_bits, pers_min_k, dual_pp_min_k;
 };
 static Tune resolve_tune(const md_conv_tune *t) {
-    Tune r = {0x7fff0000LL, 1, 2, 6, 2304, 768, 0};
+    Tune r = {0x7fff0000LL, 1, 2, 6, 2304, 768};
     if (!t) return r;
     if (t->chunk_limit > 0 && t->chunk_limit < 0x7fff0000) r.chunk_limit = t->chunk_limit;
     if (t->stream_rounds >= 1 && t->stream_rounds <= 64) r.stream_rounds = t->stream_rounds;
@@ -149,7 +149,6 @@ static Tune resolve_tune(const md_conv_tune *t) {
     if (t->stream_cache_bits & 8) r.stream_cache_bits = t->stream_cache_bits & 7;
     if (t->pers_min_k >= 1) r.pers_min_k = t->pers_min_k;
     if (t->dual_pp_min_k >= 128) r.dual_pp_min_k = t->dual_pp_min_k;
-    if (t->pp_cache_bits & 8) r.pp_cache_bits = t->pp_cache_bits & 7;
     return r;
 }
 
@@ -1286,10 +1285,10 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const unsigned voff = ((p_taps[hB * 2 + i] >> (w.tap & 31)) & 1u) ? ((unsigned)(p_base[hB * 2 + i] + soff) | dead) : OOR;
-            // a.tune bit 0: the activation stream is requested non-temporal (it should not push the weights, which every workgroup of the XCD
-            // re-reads per K tile, out of the XCD's L2)
-            if (a.tune & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(dst + i * 64 * ROWB), 16, (int)voff, 0, 0, 2);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(dst + i * 64 * ROWB), 16, (int)voff, 0, 0, 0);
+            // (not non-temporal: a linear tile reads every activation line nine times -- once per tap -- and needs the L2 for eight of them;
+            // r03 PMC with nt: 4.3 x the L2-miss traffic.  And no run-time switch here: a uniform branch around these DMAs split the
+            // phase's basic block and cost the one-tile form 10 % -- found by a same-box comparison against the round-2 tree)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(dst + i * 64 * ROWB), 16, (int)voff, 0, 0, 0);
         }
     };
 
@@ -1304,9 +1303,8 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
             // The halo is requested NON-TEMPORAL: every line is read once per tile (its neighbours' reads of the shared halo columns come within
             // microseconds), so it need not push the weights -- re-read by every workgroup of the XCD per K tile -- out of the XCD's L2.
             // r03 PMC (60 x 200 x 336, head form): L2-miss traffic 2.43 -> 2.27 GB per launch = 1.11 x the algorithmic bytes (1.28 x on linear
-            // tiles, whose nine reads per line need the L2 and get 4.3 x the traffic under nt).  a.tune bit 1 switches it off (A/B).
-            if (!(a.tune & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)dst, 16, (int)(real ? off : OOR), (c < nch ? c : 0) * (BK * 2), 0, 2);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)dst, 16, (int)(real ? off : OOR), (c < nch ? c : 0) * (BK * 2), 0, 0);
+            // tiles, whose nine reads per line need the L2 and get 4.3 x the traffic under nt); step time unchanged (same-box A/B).
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)dst, 16, (int)(real ? off : OOR), (c < nch ? c : 0) * (BK * 2), 0, 2);
         }
     };
 
@@ -1949,8 +1947,9 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     a.res_up = at->res_upsample != 0 && params[3] != nullptr;
     // one LDS staging buffer by default: measured r01 (tools/conv_ab.py), 4 resident workgroups per CU with a serial
     // DMA -> MFMA loop beat 2 double-buffered ones on every benchmark layer (+8...43 %); variant 2 keeps the double buffer
-    a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 25 || at->variant == 30 || at->variant == 31 || at->variant == 32 || at->variant == 33;
-    a.tune = tn.pp_cache_bits;   // ping-pong kernel cache policy (conv1x1_stream_kernel sets its own in its launcher)
+    // (every "auto, except ..." code counts as auto here: r03's first A/Bs of 34 / 35 / 39 / 40 ran their arm on the double-buffered loop
+    // and read 1.5 ms per step too slow)
+    a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 25 || (at->variant >= 30 && at->variant <= 40);
     a.stamp = 0; a.dbg = nullptr;
     if ((at->variant >= 17 && at->variant <= 19) || at->variant == 25 || at->variant == 26) {
         // timing ablations / stamp builds: wrong results by construction, so not part of the product library

@@ -16,8 +16,7 @@ from . import _lib
 class ConvTune(ctypes.Structure):
     """md_conv_tune: per-call tuning knobs of the conv family (all zero = the library's defaults; nothing persists in the library)."""
     _fields_ = [("chunk_limit", ctypes.c_int32), ("stream_rounds", ctypes.c_int32), ("stream_wgs_per_cu", ctypes.c_int32),
-                ("stream_cache_bits", ctypes.c_int32), ("pers_min_k", ctypes.c_int32), ("dual_pp_min_k", ctypes.c_int32),
-                ("pp_cache_bits", ctypes.c_int32)]
+                ("stream_cache_bits", ctypes.c_int32), ("pers_min_k", ctypes.c_int32), ("dual_pp_min_k", ctypes.c_int32)]
 
 
 class _ConvAttrs(ctypes.Structure):
@@ -104,8 +103,7 @@ def conv_out_hw(h, w, pc):
 import os as _os
 # A/B knobs (tools): MD_DUAL_PP_MIN_K = concatenated K from which md_conv1x1_dual runs on the ping-pong kernel, MD_PERS_MIN_K = K from
 # which the persistent ping-pong form is the dispatcher's choice.  They travel in every call's attribute struct (md_conv_tune).
-TUNE = ConvTune(dual_pp_min_k=int(_os.environ.get("MD_DUAL_PP_MIN_K", "0")), pers_min_k=int(_os.environ.get("MD_PERS_MIN_K", "0")),
-                pp_cache_bits=int(_os.environ.get("MD_PP_CACHE_BITS", "0")))
+TUNE = ConvTune(dual_pp_min_k=int(_os.environ.get("MD_DUAL_PP_MIN_K", "0")), pers_min_k=int(_os.environ.get("MD_PERS_MIN_K", "0")))
 CONV_VARIANT = int(_os.environ.get("MD_CONV_VARIANT", "0"))  # 0 auto; other values force a kernel variant (A/B measurements, see md_conv2d_attrs; 31 = auto without conv1x1_stream_kernel)
 
 

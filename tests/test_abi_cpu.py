@@ -49,13 +49,13 @@ def test_no_process_wide_tuning_setters_and_reserved0_is_checked():
         assert not hasattr(lib, n), f"{n}: a process-wide knob is back in the product library"
     from minddet_amd import nn_ops
 
-    # the ctypes mirror has the header's field list (23 int32 + 7 int32 of md_conv_tune)
+    # the ctypes mirror has the header's field list (23 int32 + 6 int32 of md_conv_tune)
     m = re.search(r"typedef struct md_conv2d_attrs \{(.*?)\} md_conv2d_attrs;", hdr, flags=re.S)
     body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
     n_i32 = sum(len(d.split(",")) for d in re.findall(r"int32_t\s+([^;]+);", body))
     assert n_i32 == 23 and "md_conv_tune tune;" in body
-    assert ctypes.sizeof(nn_ops._ConvAttrs) == 4 * (23 + 7) and ctypes.sizeof(nn_ops.ConvTune) == 28
-    assert ctypes.sizeof(nn_ops._DualAttrs) == 4 * (2 + 7)
+    assert ctypes.sizeof(nn_ops._ConvAttrs) == 4 * (23 + 6) and ctypes.sizeof(nn_ops.ConvTune) == 24
+    assert ctypes.sizeof(nn_ops._DualAttrs) == 4 * (2 + 6)
     # reserved0 != 0 -> rc 2; dummy host pointers are never dereferenced on this path
     n = 5
     dummy = (ctypes.c_char * 64)()
