@@ -102,6 +102,7 @@ __device__ __forceinline__ int bn_swz(int row, int chunk) { return row * BN_ROWB
 // All three round where the layer-by-layer path rounds (conv3 -> bf16, residual -> bf16, sum -> bf16): bit-identical to it.
 // 8 waves per workgroup, two workgroups per CU = 4 waves per SIMD: r02 stamps (tools/bottleneck_stamps.py) of the 4-wave form showed
 // every phase latency-bound at 2 waves per SIMD (27 % MFMA-busy, HBM traffic already at the algorithmic minimum).
+constexpr bool M2_SLAB = false;   // MODE 2 on the slab form of phase C: 2 spilled registers at the 128-register budget (scratch costs ~7 %): off
 template <int MODE>
 __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) {
     typedef __attribute__((address_space(3))) void lds_void;
@@ -168,13 +169,15 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
     bn_f32x16 acc1[2];
     // phase C ownership: wave (wc, wq) = output quarters 2 wc + {0, 1} x pixels 32 wq .. + 31.  This lane's four 16-B pieces of a quarter
     // (the read-out of the wave's 16-pixel slab, twice): piece i = h * 2 + it -> pixel 32 wq + 16 h + 8 it + lane / 8, 16-B chunk lane & 7
-    bn_u32x4 rres[2][4];
-    int res_lds[4];   // IDENT: where that piece of the residual sits in an x chunk (halo row of the centre pixel, swizzled chunk)
+    bn_u32x4 rres[MODE == 2 ? 1 : 2][MODE == 2 ? 1 : 4];
+    int res_lds[4] = {0, 0, 0, 0};   // IDENT: where that piece of the residual sits in an x chunk (halo row of the centre pixel, swizzled chunk)
+    if constexpr (MODE == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = 32 * wq + 8 * i + (lane >> 3), cc = lane & 7;
-        const int r = ((p >> 4) + 1) * BN_HW + (p & 15) + 1;
-        res_lds[i] = bn_swz(r, cc);
+        for (int i = 0; i < 4; ++i) {
+            const int p = 32 * wq + 8 * i + (lane >> 3), cc = lane & 7;
+            const int r = ((p >> 4) + 1) * BN_HW + (p & 15) + 1;
+            res_lds[i] = bn_swz(r, cc);
+        }
     }
     dma_chunk_a(0, 0);
     if (a.nch > 1) dma_chunk_a(1, 1);
@@ -204,19 +207,21 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) fx[kk] = *reinterpret_cast<const bn_bf16x8 *>(Xt + bn_swz(rc, 2 * kk + lh));
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {   // q = q2 * 2 + f: cout rows 64 (2 wc + q2) + 32 f .. + 31 (the tiles this wave owns again in phase C)
-                const int row0 = 64 * (2 * wc + (q >> 1)) + 32 * (q & 1);
+            // (the row expressions are written out in place: a hoisted `row0 = 64 q + 32 wc` cost this instantiation 9 spilled registers, and
+            // with scratch in use the kernel ran 7 % slower -- r03, found by bisecting against the round-2 source)
+            for (int q = 0; q < 4; ++q) {   // the (quarter, cout fragment) tiles this wave owns again in phase C: M2_SLAB: cout rows
+                                            // 64 (2 wc + q / 2) + 32 (q & 1) .., else 64 q + 32 wc ..
                 bn_f32x16 accd;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) accd[e] = 0.f;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const bn_bf16x8 fa = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_B + bn_swz(row0 + lr, 2 * kk + lh));
+                    const bn_bf16x8 fa = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_B + bn_swz((M2_SLAB ? 64 * (2 * wc + (q >> 1)) + 32 * (q & 1) : 64 * q + 32 * wc) + lr, 2 * kk + lh));
                     accd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fx[kk], accd, 0, 0, 0);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const bn_f32x4 bv = *reinterpret_cast<const bn_f32x4 *>(bias12 + 128 + row0 + 8 * g + 4 * lh);
+                    const bn_f32x4 bv = *reinterpret_cast<const bn_f32x4 *>(bias12 + 128 + (M2_SLAB ? 64 * (2 * wc + (q >> 1)) + 32 * (q & 1) : 64 * q + 32 * wc) + 8 * g + 4 * lh);
                     resd[q][2 * g + 0] = bn_pk_bf16(accd[4 * g + 0] + bv.x, accd[4 * g + 1] + bv.y);
                     resd[q][2 * g + 1] = bn_pk_bf16(accd[4 * g + 2] + bv.z, accd[4 * g + 3] + bv.w);
                 }
@@ -343,103 +348,174 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
             *reinterpret_cast<bn_u32x2 *>(T2 + pB * BN_ROWB + (((4 * wc + g) ^ ((pB >> 1) & 7)) << 4) + 8 * lh) = pk;
         }
     }
-    // this lane's four 16-B pieces of a quarter in global memory, as byte offsets behind the tile's first pixel (buffer descriptors based
-    // there: 32-bit lane offsets, pixels outside the image dropped / read as zero by the hardware range check)
-    constexpr unsigned OOR_Y = 0x80000000u;
-    unsigned y_off[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = 32 * wq + 8 * i + (lane >> 3), cc = lane & 7;
-        const int yy = y0 + (p >> 4), xx = x0 + (p & 15);
-        y_off[i] = (yy < a.H && xx < a.W) ? (unsigned)((((p >> 4) * a.W + (p & 15)) * 256 + cc * 8) * 2) : OOR_Y;
-    }
-    const long long pix00 = ((long long)n * a.H + y0) * a.W + x0;
-    const long long y_rem = ((long long)a.N * a.H * a.W - pix00) * 512;
-    __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + pix00 * 256), 0, (int)(y_rem > 0x7fffffffLL ? 0x7fffffffLL : y_rem), 0x00020000);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    BN_STAMP(7);
+    if constexpr (MODE == 2 && !M2_SLAB) {
+    // ---- MODE 2 keeps the round-2 phase C (four 64-channel quarters through a shared 18-KiB transpose image, two raw barriers per quarter):
+    // with the downsample conv's 32 value registers live, the slab form below needs more than the 128-register budget of four waves per SIMD
+    // and measured 5.6 % slower on this block (r03, same box, tools/bottleneck_ab.py); the identity / residual-tensor blocks gain 2.1 % on it.
+        // this thread's two 16-B pieces of a quarter's image in global memory
+        long long g_off[2];
+    #pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = tid + 512 * it, p = e >> 3, cc = e & 7;
+            const int yy = y0 + (p >> 4), xx = x0 + (p & 15);
+            g_off[it] = (yy < a.H && xx < a.W) ? ((long long)(n * a.H + yy) * a.W + xx) * 256 + cc * 8 : -1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        BN_STAMP(7);
 
-    // ---- phase C: y = relu(W3 . T2 + b3 + residual); this wave: output quarters 2 wc, 2 wc + 1 of its 32 pixels, no workgroup barrier
-    const float *bias3 = reinterpret_cast<const float *>(smem + BN_C);
-    char *slab = smem + BN_B + wave * 2560;   // 16 pixels x 64 channels, 144-B rows (region B: T1 is consumed)
-    if constexpr (MODE == 1) {   // a separate residual tensor: all 8 pieces requested now, behind every DMA of the tile
-        __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)(a.res + pix00 * 256), 0, (int)(y_rem > 0x7fffffffLL ? 0x7fffffffLL : y_rem), 0x00020000);
-#pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                rres[q2][i] = __builtin_bit_cast(bn_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)y_off[i], (2 * wc + q2) * 128, 2));
-    }
-    // the pixel operand (T2 fragments) is the same for both quarters: read once
-    bn_bf16x8 fbc[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) fbc[kk] = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_D + bn_swz(32 * wq + lr, 2 * kk + lh));
-#pragma unroll
-    for (int q2 = 0; q2 < 2; ++q2) {
-        const int q = 2 * wc + q2;   // output channels 64 q .. 64 q + 63
-        // bias (+ the fused downsample conv's value, ReLU) -> bf16, in accumulator layout: lane = pixel lr, 4 consecutive channels per group.
-        // One 32-channel fragment at a time (its accumulator dies into 8 packed registers before the next starts: register budget 128)
-        unsigned pkv[2][8];
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
+        // ---- phase C: y = relu(W3 . T2 + b3 + residual), 64 output channels at a time = 2 cout x 4 pixel fragments per quarter
+        const float *bias3 = reinterpret_cast<const float *>(smem + BN_C);
+        char *E = smem + BN_B;
+        // the pixel operand (T2 fragments) is the same for all four quarters: read once; the weight fragments of quarter q + 1 are
+        // requested before quarter q's epilogue (W3 is read-only in this phase: no hazard with the image barriers)
+        bn_bf16x8 fbc[4], fac[2][4];
+    #pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fbc[kk] = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_D + bn_swz(32 * wq + lr, 2 * kk + lh));
+            fac[0][kk] = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_A + bn_swz(32 * wc + lr, 2 * kk + lh));
+        }
+    #pragma unroll
+        for (int q = 0; q < 4; ++q) {
             bn_f32x16 acc3;
-#pragma unroll
+    #pragma unroll
             for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
-#pragma unroll
+    #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const bn_bf16x8 fa = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_A + bn_swz(64 * q + 32 * f + lr, 2 * kk + lh));
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fbc[kk], acc3, 0, 0, 0);
+                if (q + 1 < 4) fac[(q + 1) & 1][kk] = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_A + bn_swz(64 * (q + 1) + 32 * wc + lr, 2 * kk + lh));
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fac[q & 1][kk], fbc[kk], acc3, 0, 0, 0);
             }
-#pragma unroll
+            if (q == 1) BN_STAMP(13);
+    #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const bn_f32x4 bv = *reinterpret_cast<const bn_f32x4 *>(bias3 + 64 * q + 32 * f + 8 * g + 4 * lh);
-                unsigned p0 = bn_pk_bf16(acc3[4 * g + 0] + bv.x, acc3[4 * g + 1] + bv.y);
-                unsigned p1 = bn_pk_bf16(acc3[4 * g + 2] + bv.z, acc3[4 * g + 3] + bv.w);
-                if constexpr (MODE == 2) {
-                    const unsigned r0_ = resd[q2 * 2 + f][2 * g], r1_ = resd[q2 * 2 + f][2 * g + 1];
-                    const bn_f32x2 s0 = (bn_f32x2){__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)} +
+                const int c_local = 32 * wc + 8 * g + 4 * lh;
+                const bn_f32x4 bv = *reinterpret_cast<const bn_f32x4 *>(bias3 + 64 * q + c_local);
+                bn_u32x2 pk;
+                pk.x = bn_pk_bf16(acc3[4 * g + 0] + bv.x, acc3[4 * g + 1] + bv.y);
+                pk.y = bn_pk_bf16(acc3[4 * g + 2] + bv.z, acc3[4 * g + 3] + bv.w);
+                if constexpr (MODE == 2) {   // + bf16(Wd . x + bd), ReLU: the final value goes into the image
+                    const unsigned r0_ = resd[q][2 * g], r1_ = resd[q][2 * g + 1];
+                    const bn_f32x2 s0 = (bn_f32x2){__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u)} +
                                         (bn_f32x2){__uint_as_float(r0_ << 16), __uint_as_float(r0_ & 0xffff0000u)};
-                    const bn_f32x2 s1 = (bn_f32x2){__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)} +
+                    const bn_f32x2 s1 = (bn_f32x2){__uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)} +
                                         (bn_f32x2){__uint_as_float(r1_ << 16), __uint_as_float(r1_ & 0xffff0000u)};
-                    p0 = bn_pk_relu(bn_pk_bf16(s0.x, s0.y));
-                    p1 = bn_pk_relu(bn_pk_bf16(s1.x, s1.y));
+                    pk.x = bn_pk_relu(bn_pk_bf16(s0.x, s0.y));
+                    pk.y = bn_pk_relu(bn_pk_bf16(s1.x, s1.y));
                 }
-                pkv[f][2 * g] = p0; pkv[f][2 * g + 1] = p1;
+                *reinterpret_cast<bn_u32x2 *>(E + pB * BN_ES + c_local * 2) = pk;
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (q2 == 0) BN_STAMP(13);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {   // pixels 16 h .. 16 h + 15 of the wave's 32: lanes lr >> 4 == h hold them
-            if ((lr >> 4) == h) {
-#pragma unroll
-                for (int f = 0; f < 2; ++f)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<bn_u32x2 *>(slab + (lr & 15) * BN_ES + f * 64 + 16 * g + 8 * lh) = (bn_u32x2){pkv[f][2 * g], pkv[f][2 * g + 1]};
-            }
-            // The slab is read back by OTHER lanes of the wave, in another vector type: without a compiler-level ordering point hipcc
-            // duplicated the read-out into the lanes that skip the write block and ran it FIRST (stale rows in exactly those lanes' pieces;
-            // found by the bit-compare test).  LDS operations of one wave execute in issue order: no hardware wait is needed.
-            asm volatile("" ::: "memory");
-#pragma unroll
+            BN_BAR_RAW();   // raw barriers in this loop: __syncthreads() would wait for the previous quarter's stores to COMPLETE (vmcnt 0)
+            if (q == 1) BN_STAMP(14);
+    #pragma unroll
             for (int it = 0; it < 2; ++it) {
-                bn_u32x4 v = *reinterpret_cast<const bn_u32x4 *>(slab + (8 * it + (lane >> 3)) * BN_ES + (lane & 7) * 16);
-                if constexpr (MODE != 2) {
-                    const bn_u32x4 rv = rres[q2][h * 2 + it];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const bn_f32x2 sum = (bn_f32x2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)} +
-                                             (bn_f32x2){__uint_as_float(rv[k] << 16), __uint_as_float(rv[k] & 0xffff0000u)};
-                        v[k] = bn_pk_relu(bn_pk_bf16(sum.x, sum.y));
-                    }
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, (int)y_off[h * 2 + it], q * 128, 2);
+                if (g_off[it] < 0) continue;
+                const int e = tid + 512 * it;
+                bn_u32x4 v = *reinterpret_cast<const bn_u32x4 *>(E + (e >> 3) * BN_ES + (e & 7) * 16);
+                __builtin_nontemporal_store(v, reinterpret_cast<bn_u32x4 *>(a.y + g_off[it] + 64 * q));
             }
-            asm volatile("" ::: "memory");   // ... and the next half's writes stay behind this half's reads
+            if (q == 1) BN_STAMP(15);
+            BN_BAR_RAW();      // the image is rewritten by the next quarter
+            BN_STAMP(8 + q);
         }
-        BN_STAMP(8 + q2);
+    } else {
+        // this lane's four 16-B pieces of a quarter in global memory, as byte offsets behind the tile's first pixel (buffer descriptors based
+        // there: 32-bit lane offsets, pixels outside the image dropped / read as zero by the hardware range check)
+        constexpr unsigned OOR_Y = 0x80000000u;
+        unsigned y_off[4];
+    #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = 32 * wq + 8 * i + (lane >> 3), cc = lane & 7;
+            const int yy = y0 + (p >> 4), xx = x0 + (p & 15);
+            y_off[i] = (yy < a.H && xx < a.W) ? (unsigned)((((p >> 4) * a.W + (p & 15)) * 256 + cc * 8) * 2) : OOR_Y;
+        }
+        const long long pix00 = ((long long)n * a.H + y0) * a.W + x0;
+        const long long y_rem = ((long long)a.N * a.H * a.W - pix00) * 512;
+        __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + pix00 * 256), 0, (int)(y_rem > 0x7fffffffLL ? 0x7fffffffLL : y_rem), 0x00020000);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        BN_STAMP(7);
+
+        // ---- phase C: y = relu(W3 . T2 + b3 + residual); this wave: output quarters 2 wc, 2 wc + 1 of its 32 pixels, no workgroup barrier
+        const float *bias3 = reinterpret_cast<const float *>(smem + BN_C);
+        char *slab = smem + BN_B + wave * 2560;   // 16 pixels x 64 channels, 144-B rows (region B: T1 is consumed)
+        if constexpr (MODE == 1) {   // a separate residual tensor: all 8 pieces requested now, behind every DMA of the tile
+            __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)(a.res + pix00 * 256), 0, (int)(y_rem > 0x7fffffffLL ? 0x7fffffffLL : y_rem), 0x00020000);
+    #pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+    #pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    rres[q2][i] = __builtin_bit_cast(bn_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)y_off[i], (2 * wc + q2) * 128, 2));
+        }
+        // the pixel operand (T2 fragments) is the same for both quarters: read once
+        bn_bf16x8 fbc[4];
+    #pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fbc[kk] = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_D + bn_swz(32 * wq + lr, 2 * kk + lh));
+    #pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+            const int q = 2 * wc + q2;   // output channels 64 q .. 64 q + 63
+            // bias (+ the fused downsample conv's value, ReLU) -> bf16, in accumulator layout: lane = pixel lr, 4 consecutive channels per group.
+            // One 32-channel fragment at a time (its accumulator dies into 8 packed registers before the next starts: register budget 128)
+            unsigned pkv[2][8];
+    #pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                bn_f32x16 acc3;
+    #pragma unroll
+                for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
+    #pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const bn_bf16x8 fa = *reinterpret_cast<const bn_bf16x8 *>(smem + BN_A + bn_swz(64 * q + 32 * f + lr, 2 * kk + lh));
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fbc[kk], acc3, 0, 0, 0);
+                }
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const bn_f32x4 bv = *reinterpret_cast<const bn_f32x4 *>(bias3 + 64 * q + 32 * f + 8 * g + 4 * lh);
+                    unsigned p0 = bn_pk_bf16(acc3[4 * g + 0] + bv.x, acc3[4 * g + 1] + bv.y);
+                    unsigned p1 = bn_pk_bf16(acc3[4 * g + 2] + bv.z, acc3[4 * g + 3] + bv.w);
+                    if constexpr (MODE == 2) {
+                        const unsigned r0_ = resd[q2 * 2 + f][2 * g], r1_ = resd[q2 * 2 + f][2 * g + 1];
+                        const bn_f32x2 s0 = (bn_f32x2){__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)} +
+                                            (bn_f32x2){__uint_as_float(r0_ << 16), __uint_as_float(r0_ & 0xffff0000u)};
+                        const bn_f32x2 s1 = (bn_f32x2){__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)} +
+                                            (bn_f32x2){__uint_as_float(r1_ << 16), __uint_as_float(r1_ & 0xffff0000u)};
+                        p0 = bn_pk_relu(bn_pk_bf16(s0.x, s0.y));
+                        p1 = bn_pk_relu(bn_pk_bf16(s1.x, s1.y));
+                    }
+                    pkv[f][2 * g] = p0; pkv[f][2 * g + 1] = p1;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (q2 == 0) BN_STAMP(13);
+    #pragma unroll
+            for (int h = 0; h < 2; ++h) {   // pixels 16 h .. 16 h + 15 of the wave's 32: lanes lr >> 4 == h hold them
+                if ((lr >> 4) == h) {
+    #pragma unroll
+                    for (int f = 0; f < 2; ++f)
+    #pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<bn_u32x2 *>(slab + (lr & 15) * BN_ES + f * 64 + 16 * g + 8 * lh) = (bn_u32x2){pkv[f][2 * g], pkv[f][2 * g + 1]};
+                }
+                // The slab is read back by OTHER lanes of the wave, in another vector type: without a compiler-level ordering point hipcc
+                // duplicated the read-out into the lanes that skip the write block and ran it FIRST (stale rows in exactly those lanes' pieces;
+                // found by the bit-compare test).  LDS operations of one wave execute in issue order: no hardware wait is needed.
+                asm volatile("" ::: "memory");
+    #pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    bn_u32x4 v = *reinterpret_cast<const bn_u32x4 *>(slab + (8 * it + (lane >> 3)) * BN_ES + (lane & 7) * 16);
+                    if constexpr (MODE != 2) {
+                        const bn_u32x4 rv = rres[q2][h * 2 + it];
+    #pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bn_f32x2 sum = (bn_f32x2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)} +
+                                                 (bn_f32x2){__uint_as_float(rv[k] << 16), __uint_as_float(rv[k] & 0xffff0000u)};
+                            v[k] = bn_pk_relu(bn_pk_bf16(sum.x, sum.y));
+                        }
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, (int)y_off[h * 2 + it], q * 128, 2);
+                }
+                asm volatile("" ::: "memory");   // ... and the next half's writes stay behind this half's reads
+            }
+            BN_STAMP(8 + q2);
+        }
     }
 #ifdef MD_DIAG
     if (a.dbg && blockIdx.x == (gridDim.x / 2) && tid == 0) {
