@@ -101,11 +101,11 @@ def test_product_never_imports_oracle():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    """profiles/r02_bench.json is the bench.py line of the profiled run: the driver's contract fields, the roofline object and the
+    """profiles/r03_bench.json is the bench.py line of the profiled run: the driver's contract fields, the roofline object and the
     cpu_baseline object must all be there (a schema regression in bench.py shows up when the profile is regenerated)."""
     import json
 
-    line = open(os.path.join(ROOT, "profiles", "r02_bench.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, "profiles", "r03_bench.json")).read().strip().splitlines()[-1]
     j = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
@@ -125,3 +125,6 @@ def test_committed_bench_line_has_the_contract_fields():
     assert ro["kind"] == "reference" and ro["boxes_iou_nms"]["keep_lists_identical"] is True and ro["boxes_iou_bev"]["cpu_ms"] > 0
     assert r["zero_operands"]["zero_frac"] >= r["zero_operands"]["random_frac"] and j["from_uint8"]["ms_per_step"] > 0
     assert j["nms_prefix"]["image_slots_flagged"] == 0 and j["n_gpus"] == 1
+    # round 3: the host's enqueue cost beside the step time (multi-GPU readiness), PMC traffic present only because the file's kernel-source
+    # hash matched the build that ran
+    assert 0 < j["host_enqueue_ms_single_step"] < 0.25 * j["ms_per_step"] and r["traffic"] is not None and r["traffic"] >= r["algorithmic_mb_per_launch"]

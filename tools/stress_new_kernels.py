@@ -1,4 +1,5 @@
-"""Race hunt: the persistent ping-pong form (variant 32), the stream kernel (30) and md_stem_conv run many times on the same operands;
+"""Race hunt: the persistent ping-pong form (variant 32), its HALO forms (36 / 37 / 38, the fused head with 34), the stream kernel (30), md_bottleneck
+and md_stem_conv run many times on the same operands;
 every output must equal the first one and the reference kernel's bit for bit.  python tools/stress_new_kernels.py [reps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +13,9 @@ bad = 0
 CASES = [("pers 3x3 256 b30 P2", 32, 15, (30, 200, 336, 256), 256, 3, False), ("pers 3x3 256 @50x84", 32, 15, (60, 50, 84, 256), 256, 3, False),
          ("pers 3x3 512 @25x42", 32, 15, (60, 25, 42, 512), 512, 3, False), ("pers 1x1 1024->256", 32, 15, (60, 50, 84, 1024), 256, 1, False),
          ("stream 256->1024 +res", 30, 20, (60, 50, 84, 256), 1024, 1, True), ("stream 512->256", 30, 20, (60, 100, 168, 512), 256, 1, False),
-         ("stream 256->256 +res", 30, 20, (60, 100, 168, 256), 256, 1, True)]
+         ("stream 256->256 +res", 30, 20, (60, 100, 168, 256), 256, 1, True),
+         ("halo mf1 3x3 256 b30 P2", 37, 22, (30, 200, 336, 256), 256, 3, False), ("halo mf0 3x3 256 @100x168 +res", 36, 15, (30, 100, 168, 256), 256, 3, True),
+         ("halo pers 3x3 256 b30 P2", 38, 22, (30, 200, 336, 256), 256, 3, False), ("halo mf1 3x3 128->512 @41x77", 37, 22, (16, 41, 77, 128), 512, 3, False)]
 for name, v, vref, xs, cout, k, res in CASES:
     cin = xs[3]
     w = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (k * k * cin)) ** 0.5
@@ -31,6 +34,34 @@ for name, v, vref, xs, cout, k, res in CASES:
             n_bad += 1
     bad += n_bad
     print(f"{name}: {REPS} runs, {n_bad} mismatches", flush=True)
+# fused RPN head on the HALO form against the linear-tile form
+w1 = torch.randn((256, 256, 3, 3), generator=g) * (2.0 / 2304) ** 0.5
+pc = nn_ops.pack_conv(w1, bias=torch.randn((256,), generator=g) * 0.1, stride=1, pad=1, relu=True).to(dev)
+pc2 = nn_ops.pack_conv(torch.randn((15, 256, 1, 1), generator=g) * 0.05, bias=torch.randn((15,), generator=g) * 0.1).to(dev)
+for (n, h, w_) in ((30, 200, 336), (30, 100, 168)):
+    x = torch.randn((n, h, w_, 256), generator=g).to(torch.bfloat16).to(dev)
+    ref = nn_ops.conv2d_head(x, pc, pc2, variant=35)
+    n_bad = sum(0 if torch.equal(nn_ops.conv2d_head(x, pc, pc2, variant=34), ref) else 1 for _ in range(REPS))
+    bad += n_bad
+    print(f"head halo {n}x{h}x{w_}: {REPS} runs, {n_bad} mismatches", flush=True)
+# md_bottleneck (identity / first block) against the three launches
+import importlib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+for cin, ds in ((256, False), (64, True)):
+    w1 = torch.randn((64, cin, 1, 1), generator=g) * (2.0 / cin) ** 0.5
+    w2 = torch.randn((64, 64, 3, 3), generator=g) * (2.0 / 576) ** 0.5
+    w3 = torch.randn((256, 64, 1, 1), generator=g) * (2.0 / 64) ** 0.5
+    p1, p2, p3 = (nn_ops.pack_conv(w1, bias=torch.randn((64,), generator=g) * 0.1, relu=True).to(dev),
+                  nn_ops.pack_conv(w2, bias=torch.randn((64,), generator=g) * 0.1, stride=1, pad=1, relu=True).to(dev),
+                  nn_ops.pack_conv(w3, bias=torch.randn((256,), generator=g) * 0.1, relu=True).to(dev))
+    pd = nn_ops.pack_conv(torch.randn((256, cin, 1, 1), generator=g) * (1.0 / cin) ** 0.5, bias=torch.randn((256,), generator=g) * 0.1, relu=False).to(dev) if ds else None
+    blk = nn_ops.pack_bottleneck(p1, p2, p3, pd)
+    x = torch.randn((16, 200, 336, cin), generator=g).to(torch.bfloat16).to(dev)
+    res = nn_ops.conv2d(x, pd) if ds else x
+    ref = nn_ops.conv2d(nn_ops.conv2d(nn_ops.conv2d(x, p1), p2), p3, residual=res)
+    n_bad = sum(0 if torch.equal(nn_ops.bottleneck(x, blk), ref) else 1 for _ in range(REPS))
+    bad += n_bad
+    print(f"md_bottleneck Cin {cin} downsample {ds}: {REPS} runs, {n_bad} mismatches", flush=True)
 ps = nn_ops.pack_stem_conv(torch.randn((32, 3, 6, 6), generator=g) * 0.1, act="silu").to(dev)
 x4 = nn_ops.to_stem_layout(torch.randn((32, 640, 640, 8), generator=g).to(torch.bfloat16).to(dev))
 ref = nn_ops.stem_conv(x4, ps)
