@@ -1765,7 +1765,8 @@ static void pingpong_halo_tiles(ConvArgs &a) {
 // Preconditions of the HALO form (checked by the dispatcher besides the ping-pong kernel's own): 3x3 / stride 1 / pad 1 with korder-1 weights.
 static bool pingpong_halo_takes(const ConvArgs &a) {
     return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad_top == 1 && a.pad_left == 1 && a.korder == 1 && a.Cin % 64 == 0 && a.Ho == a.H &&
-           a.Wo == a.W && !a.x2 && !a.res_up && a.x_bytes != 0 && (long long)a.N * pingpong_halo_tiles_per_image(a.H, a.W, nullptr, nullptr) < 0x7fffffffLL / 8;
+           a.Wo == a.W && !a.x2 && !a.res_up && a.x_bytes != 0 && (long long)a.N * pingpong_halo_tiles_per_image(a.H, a.W, nullptr, nullptr) < 0x7fffffffLL / 8 &&
+           (long long)(15 * a.W + 32) * a.Ctot * 2 < 0x7fffffffLL;   // the persistent form's 32-bit store offsets inside a tile
 }
 
 template <int MF, bool HALO>

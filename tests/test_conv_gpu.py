@@ -764,5 +764,6 @@ def test_pingpong_halo_persistent_and_head_forms_are_bit_identical():
         pc2 = nn_ops.pack_conv(torch.randn((15, 256, 1, 1), generator=g) * 0.05, bias=torch.randn((15,), generator=g) * 0.1).to(DEV)
         x = torch.randn((n, h, w, 256), generator=g).to(torch.bfloat16).to(DEV)
         a_, b_ = nn_ops.conv2d_head(x, pc, pc2, variant=35), nn_ops.conv2d_head(x, pc, pc2, variant=34)
+        c_ = nn_ops.conv2d_head(x, pc, pc2)      # the dispatcher's own choice (HALO where its tiles fit): same bits either way
         torch.cuda.synchronize()
-        assert torch.equal(a_, b_), (n, h, w)
+        assert torch.equal(a_, b_) and torch.equal(a_, c_), (n, h, w)
