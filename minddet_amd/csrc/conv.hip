@@ -2136,7 +2136,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     }
     // a grid of fewer than two workgroups per CU with a long K loop: nobody else hides the DMA latency, stage the next tile
     // while this one is multiplied (512->512 @20x20, batch 32: +11 %)
-    if (variant == 0 && sb_blocks <= 512 && a.Kpad / BK >= 16) a.single_buf = 0;
+    if (variant == 0 && sb_blocks <= 512 && a.Kpad / BK >= 4) a.single_buf = 0;
     if (variant == 1) return launch_conv<256, 2, 2, 2, 2, 0>(a, s);               // register-staged, 64-bit addressing
     return fast ? launch_conv<256, 2, 2, 2, 2, 2>(a, s) : launch_conv<256, 2, 2, 2, 2, 1>(a, s);
 }
