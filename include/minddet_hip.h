@@ -154,7 +154,8 @@ typedef struct md_conv2d_attrs {
                                     15 / 22 256x256 ping-pong kernel (32x32x16 / 16x16x32 MFMA), 32 its persistent form, 36 / 37 / 38 its
                                     HALO form for 3x3 layers (16x16-pixel tiles, the halo staged once per channel chunk; 38 persistent);
                                     30 weight-stationary pointwise kernel; 31 / 33 / 35 = auto without the pointwise / persistent /
-                                    HALO kernel, 34 = auto with the HALO form wherever it applies; a variant whose
+                                    HALO kernel, 34 = auto with the HALO form wherever it applies, 39 / 40 = auto with the HALO form also for / instead of
+                                    the persistent form where its tiles fit (A/B records in profiles/r03_pp_halo_step_ab.txt); a variant whose
                                     preconditions do not hold falls back to the generic kernel.  17-19 and 25 (timing /
                                     stamp diagnostics that do NOT compute the convolution) exist only in the MD_DIAG build
                                     used by tools/ (libminddet_hip_diag.so); this library rejects them with MD_ERR_ARG. */
