@@ -8,7 +8,7 @@ run() {  # dir config batch
 for r in $(seq $R); do
   for cfg in "configs/faster_rcnn/faster_rcnn_r50_fpn.py 120" "configs/yolov5/yolov5s.py 32" "configs/yolov8/yolov8l.py 32" "configs/mask_rcnn/mask_rcnn_r101_fpn.py 32"; do
     set -- $cfg
-    run _r02 $1 $2
+    run ${TREE_A:-_r02} $1 $2
     run . $1 $2
   done
 done
