@@ -535,8 +535,10 @@ def main(argv=None):
         t_roof_ms = sum(max(r[2] / (PEAK_BF16_TFLOPS * 1e12), r[6] / PEAK_HBM_BPS) for r in all_recs) * 1e3
         traffic = all_traffic = None
         traffic_note = "no PMC file for this library build"
-        tp = os.path.join(ROOT, "profiles", "r03_conv_traffic.json")
-        PMC_PREFIX = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<256, 2, 2, 2, 2, 2,", 7: "bottleneck64_kernel", 8: "conv1x1_stream_kernel"}  # all instantiations of the kernel
+        tp = os.path.join(ROOT, "profiles", {"FasterRCNN": "r03_conv_traffic.json", "YOLOv5": "r03_yolov5s_conv_traffic.json",
+                                             "YOLOv8": "r03_yolov8l_conv_traffic.json"}.get(type(model).__name__, "r03_conv_traffic.json"))
+        PMC_PREFIX = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<256, 2, 2, 2, 2, 2,", 3: "conv_igemm_kernel<256, 1, 4,", 5: "conv3x3_halo_kernel",
+                      7: "bottleneck64_kernel", 8: "conv1x1_stream_kernel"}  # all instantiations of the kernel
         if os.path.exists(tp):  # PMC passes are separate rocprofv3 runs (tools/pmc_traffic.py); same config only
             tj = json.load(open(tp))
             # the PMC passes describe ONE build of the kernels: the file records the hash of the conv sources it was measured on
@@ -544,7 +546,7 @@ def main(argv=None):
             same_build = tj.get("kernel_source_sha256") == kernel_source_hash()
             traffic_note = (f"rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{os.path.basename(tp)}" if same_build else
                             f"profiles/{os.path.basename(tp)} was measured on other kernel sources: not reported")
-            if same_build and tj.get("batch_per_gpu") == B and type(model).__name__ == "FasterRCNN":
+            if same_build and tj.get("batch_per_gpu") == B and type(model).__name__ in ("FasterRCNN", "YOLOv5", "YOLOv8"):
                 all_traffic = round(tj["hbm_bytes_per_launch"] / 1e6, 2)
                 pmc_rows = [v for k_, v in tj.get("by_kernel", {}).items() if dom in PMC_PREFIX and k_.startswith(PMC_PREFIX[dom])]
                 if pmc_rows:
