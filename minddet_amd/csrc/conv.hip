@@ -1128,6 +1128,7 @@ template <int ABL, int MF = 0, int GEN = 1, bool HEAD = false, bool PERS = false
 __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     static_assert(!PERS || (!HEAD && ABL == 0 && GEN != 1), "the persistent form has the plain epilogues only");
     static_assert(!HALO || (ABL == 0 && GEN != 1), "the halo form has the plain epilogues only");
+    static_assert(!(HALO && PERS && MF == 0), "persistent + HALO exists on the 16x16x32 shape only (registers; its slab epilogue has no lane permutation)");
     constexpr int CT = 256, PT = 256, NT = 512;
     constexpr int EP_STRIDE = CT * 2 + 16;
     constexpr unsigned OOR = 0x80000000u;
@@ -1141,6 +1142,14 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
     const int wr = wave >> 2, wc = wave & 3;
     const int lr = lane & 31, lh = lane >> 5;
     const int l16 = lane & 15, lq = lane >> 4;
+    // HALO: which pixel of a fragment a lane's accumulator column is.  The halo rows a fragment read touches start at ANY row (tap shifts), and
+    // ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MICROARCH, LDS): with lane = pixel the two k-chunks a
+    // group mixes collide 2-way on 3 of 4 alignments (r03 PMC: SQ_LDS_BANK_CONFLICT 7 x the linear form's).  16x16x32: lanes 0-3 / 12-15 take the
+    // EVEN pixels of the 16, lanes 4-11 the odd ones -- a group then reads one chunk on even rows and the other on odd rows, which live in
+    // different halves of the 256-B bank window; 32x32x16: each group takes 16 consecutive pixels.  Conflict-free for every alignment
+    // (brute-forced over all of them); the output is unchanged -- only which lane computes which pixel.
+    const int hp16 = !HALO ? l16 : (l16 < 4 ? 2 * l16 : (l16 < 12 ? 2 * (l16 - 4) + 1 : 2 * (l16 - 8)));
+    const int hp32 = !HALO ? lr : (lr < 4 ? lr : (lr < 12 ? lr + 12 : (lr < 16 ? lr - 8 : (lr < 20 ? lr + 8 : (lr < 28 ? lr - 12 : lr)))));
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int ct = slot % a.n_ctiles;
     int ptl = slot / a.n_ctiles;                                        // pixel tile inside the XCD's range
@@ -1215,7 +1224,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
         }
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            const int pl = MF ? wc * 64 + r4 * 16 + l16 : wc * 64 + (r4 & 1) * 32 + lr;   // tile-local pixel of this lane in the fragment
+            const int pl = MF ? wc * 64 + r4 * 16 + hp16 : wc * 64 + (r4 & 1) * 32 + hp32;   // tile-local pixel of this lane in the fragment
             hpb[r4] = (pl >> t_twl) * t_hw + (pl & ((1 << t_twl) - 1));
         }
         return;
@@ -1589,7 +1598,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
                         u32x2 pk;
                         pk.x = pk_bf16(v0, v1);
                         pk.y = pk_bf16(v2, v3);
-                        *reinterpret_cast<u32x2 *>(slab + l16 * 144 + (ii * 16 + 4 * lq) * 2) = pk;
+                        *reinterpret_cast<u32x2 *>(slab + hp16 * 144 + (ii * 16 + 4 * lq) * 2) = pk;
                     }
                     flush_slab(j4 * 16, q * 64);
                 }
@@ -1610,7 +1619,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
             const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + c_local);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int p_local = wc * 64 + j * 16 + l16;
+                const int p_local = wc * 64 + j * 16 + hp16;
                 float v0 = acc4[i][j][0] + bv.x, v1 = acc4[i][j][1] + bv.y, v2 = acc4[i][j][2] + bv.z, v3 = acc4[i][j][3] + bv.w;
                 if (a.relu == 1 && !a.res) {
                     v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
@@ -1632,7 +1641,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
             const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + c_local);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int p_local = wc * 64 + j * 32 + lr;
+                const int p_local = wc * 64 + j * 32 + hp32;
                 // packed adds (v_pk_add_f32), one-instruction bf16 pack, ReLU on the packed pair: 8 VALU per 4 values
                 f32x2 s01 = (f32x2){acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
                 f32x2 s23 = (f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
@@ -2058,11 +2067,14 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     const long long halo_tiles = (long long)a.N * pingpong_halo_tiles_per_image(a.H, a.W, nullptr, nullptr);
     const bool halo_plain_out = !a.adv || (a.os == 1 && a.oy == 0 && a.ox == 0 && a.Ho == a.Hf && a.Wo == a.Wf);
     const bool halo_ok_pp = fast && dma_ok && pingpong_halo_takes(a) && halo_plain_out && a.Cout % 256 == 0;
-    // r03 tools/pp_halo_ab.py (batch 60, same box, interleaved, bit-identical): the fused-head form gains 6.3 % on 200x336 (0.2 % idle tile
-    // pixels) and 3.2 % on 100x168 (9 % idle), loses 13 % on 50x84 (22 % idle); the one-tile form gains 4 % on 200x336 but stays behind the
-    // persistent linear-tile form (which the persistent HALO form only equals) -> auto for the head form where the tiles fit
-    const bool halo_auto = halo_ok_pp && !no_halo && head != nullptr && (double)M >= 0.90 * (double)(halo_tiles * 256);
-    const bool halo_pp = halo_ok_pp && (force_halo || halo_auto || (halo_fit && (double)M >= 0.99 * (double)(halo_tiles * 256)));
+    // r03 tools/pp_halo_ab.py (batch 60, same box, interleaved, bit-identical; with the conflict-free lane -> pixel map): on 200x336 (0.2 % idle
+    // tile pixels) the fused-head form gains 10.3 %, the persistent form 3.4 %, the one-tile form 8.5 % (= the persistent HALO form); on
+    // 100x168 (9 % idle) the head form +3.7 %, the persistent form -3 %; on 50x84 (22 % idle) everything loses 8-14 %.  In the step
+    // (profiles/r03_pp_halo_step_ab.txt): head form -0.59 ms, persistent P2 form another -0.40 ms -> auto for the head form from 90 % tile
+    // efficiency, for the persistent form from 99 %
+    const double halo_eff = (double)M / (double)(halo_tiles * 256);
+    const bool halo_auto = halo_ok_pp && !no_halo && ((head != nullptr && halo_eff >= 0.90) || (!halo_not_pers && halo_eff >= 0.99));
+    const bool halo_pp = halo_ok_pp && (force_halo || halo_auto || (halo_fit && halo_eff >= 0.99));
     if (head) {
         if (!(fast && dma_ok && a.Cout == 256 && !a.adv && !a.res && a.relu == 1 && pp_blocks >= 64)) return MD_ERR_UNSUPPORTED_INTERNAL;
         a.w2 = head->w2; a.b2 = head->b2; a.y2 = head->y2;
