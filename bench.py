@@ -65,6 +65,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-from-uint8", action="store_true", help="skip the extra from-uint8 pass (from_uint8 in the line)")
     ap.add_argument("--paste-masks", action="store_true",
                     help="Mask R-CNN configs: paste the 28x28 masks into the image inside the step (md_paste_masks -> [B,max_det,H,W/32] bit masks)")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="run the batch as this many equal parts, each on its own HIP stream (graphs.SplitForward; default: the config's "
+                         "test_cfg.streams, 1 when absent).  With more than one stream the roofline block is measured in a serialized "
+                         "single-stream pass AFTER the timed region (a launch's duration under overlap includes the other stream's share of the CUs)")
     ap.add_argument("--no-zero-operands", action="store_true",
                     help="skip the zero-operand replay of the dominant kernel (roofline.zero_operands)")
     return ap.parse_args(argv)
@@ -429,8 +433,21 @@ def main(argv=None):
         images_u8, pre_mat = make_u8()
         preprocess = lambda: nn_ops.image_preprocess(images_u8, pre_mat, MEAN, STD, (H, W), stem_layout=images.shape[3] == 4)  # noqa: E731
 
+    n_streams = args.streams if args.streams is not None else int(getattr(model, "streams", 1))
+    if n_streams > 1 and (B % n_streams or not hasattr(model, "forward_split")):
+        sys.stderr.write(f"bench.py: --streams {n_streams} needs a batch divisible by it and a detector with forward_split\n")
+        return 2
+    splitter = None
+    if n_streams > 1:
+        from minddet_amd.graphs import SplitForward
+
+        splitter = model.forward_split if model.forward_split.n == n_streams else SplitForward(model, n_streams)
+    serial = {"on": False}   # streams > 1: the bracketed passes (roofline) run the whole batch on one stream
+
     def forward(x):
         bracket["idx"] = 0
+        if splitter is not None and not serial["on"]:
+            return splitter(x)
         return model.forward(x)
 
     def gatherer(out):   # Mask R-CNN: the 28x28 masks travel as fp16 in a second fixed-shape all_gather
@@ -447,13 +464,17 @@ def main(argv=None):
         captured = CapturedStep(lambda xx: tuple(model.forward(xx))[:2], images)
         step, finish = (lambda: captured(images)), (lambda: None)   # noqa: E731
     instrument = not args.no_roofline
+    if splitter is not None and instrument and (args.bracket != "dominant" or args.dump_convs or args.warmup < 1):
+        raise SystemExit("bench.py: with --streams > 1 the roofline pass is --bracket dominant, --warmup >= 1, no --dump-convs (use --streams 1 for those)")
     survey = []            # records of ONE fully bracketed step (the last warmup step): the whole-set table in --bracket dominant
     dominant_only = instrument and args.bracket == "dominant" and args.warmup >= 1 and not args.dump_convs
 
     def on_warmup(w_i, step_):
         if dominant_only and w_i == args.warmup - 1:
             instrument_on()
+            serial["on"] = True
             step_()
+            serial["on"] = False
             instrument_off()
             torch.cuda.synchronize()
             survey.extend(records)
@@ -468,7 +489,7 @@ def main(argv=None):
                 t_k[r[7]] = t_k.get(r[7], 0.0) + r[0].elapsed_time(r[1])
             dom_id = max(t_k, key=t_k.get)
             bracket["calls"] = frozenset(i for i, r in enumerate(survey) if r[7] == dom_id)   # dispatch is deterministic per call site
-        if instrument:
+        if instrument and splitter is None:
             instrument_on()
 
     def all_reduce_max(v):
@@ -479,6 +500,16 @@ def main(argv=None):
     dt = run_timed(step, finish, args.steps, args.warmup, use_dist, torch.cuda.synchronize,
                    lambda: dist.barrier(device_ids=[local_rank]), all_reduce_max, before_timed, on_warmup)
     instrument_off()
+    if instrument and splitter is not None and survey:
+        # two streams: the dominant kernel's launches are bracketed in a serialized pass of the same steps on ONE stream, outside `dt`
+        serial["on"] = True
+        instrument_on()
+        for _ in range(max(args.steps, 1)):
+            step()
+        finish()
+        instrument_off()
+        serial["on"] = False
+        torch.cuda.synchronize()
     survey = survey or None
     host_enqueue_ms = None if HOST_ENQUEUE["s"] is None else HOST_ENQUEUE["s"] / max(args.steps, 1) * 1e3
     # ... and of ONE step enqueued into an empty queue (device idle before, no synchronisation until the host is done): the pure cost of
@@ -495,7 +526,7 @@ def main(argv=None):
     if not args.from_uint8 and not args.no_from_uint8 and not args.graph and rank == 0 and not use_dist and hasattr(nn_ops, "image_preprocess"):
         u8, mat = make_u8()
         pre2 = lambda: nn_ops.image_preprocess(u8, mat, MEAN, STD, (H, W), stem_layout=images.shape[3] == 4)  # noqa: E731
-        step2, finish2 = make_step(lambda xx: model.forward(xx), images, False, None, pre2)
+        step2, finish2 = make_step(forward, images, False, None, pre2)
         k2 = max(2, min(args.steps, 5))
         dt2 = run_timed(step2, finish2, k2, 1, False, torch.cuda.synchronize, None, None)
         from_u8 = {"ms_per_step": round(dt2 / k2 * 1e3, 3), "value": round(B * k2 / dt2, 2), "steps": k2,
@@ -553,8 +584,12 @@ def main(argv=None):
                     traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in pmc_rows) / sum(v["launches"] for v in pmc_rows) / 1e6, 2)
         roofline = {"bound": "hbm" if hbm_bound else "mfma",
                     "kernel": KNAMES.get(dom, str(dom)) + " (dominant kernel: %.0f %% of the conv/FC time)" % (100 * dom_share),
-                    "bracketed": "HIP events around this kernel's launches in the timed region" + (
-                        "; all_conv: every launch of the last warmup step" if survey else "; all_conv: every launch of the timed region"),
+                    "bracketed": ("HIP events around this kernel's launches in the timed region" if splitter is None else
+                                  f"HIP events around this kernel's launches in a serialized single-stream pass of {args.steps} steps AFTER the "
+                                  f"timed region (the timed region overlaps {n_streams} streams: a launch's duration there includes the other "
+                                  "stream's share of the CUs)") + (
+                        "; all_conv: every launch of the last warmup step" + (" (one stream)" if splitter is not None else "")
+                        if survey else "; all_conv: every launch of the timed region"),
                     "achieved": round(ach, 2), "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_unit": "MB per launch (" + traffic_note + ")",
                     "achieved_tflops": round(d_fl / (d_ms * 1e-3) / 1e12, 2),
@@ -699,7 +734,7 @@ def main(argv=None):
             "host_enqueue_ms_single_step": round(host_single_ms, 3),
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": wl, "batch_per_gpu": B,
+            "config": {"workload": wl, "batch_per_gpu": B, "streams": n_streams,
                        "global_batch": world * B, "parallelism": f"dp{world} (image sharding + all_gather of detections)",
                        "gmac_per_image": None if gmac is None else round(gmac, 2), "weights": "random init, seed 7"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "from_uint8": from_u8, "mask_paste": mask_paste,

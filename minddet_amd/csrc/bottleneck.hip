@@ -111,6 +111,17 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
+    // lane -> pixel of the wave's 32-pixel fragment (= two 16-pixel tile rows, 18 halo rows apart) wherever the pixel operand is read at
+    // tap-shifted halo rows (phase B; MODE 2's downsample conv): ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}
+    // {4-11, 16-19, 28-31} (+32); with pixel = lane a group straddles the two tile rows and two of its 16 halo rows coincide mod 16 = a 2-way
+    // bank conflict on every such read (r03, tools/pmc_lds_survey.sh: conflict cycles = 0.9 x the LDS-busy cycles).  hp gives each group one
+    // whole tile row.  T2 is stored at row = LANE, so phase C reads consecutive rows and its accumulator column lr is pixel hp as well.
+    // (recomputed at each use behind an opaque copy of lr: held in a register across the phases it cost MODE 2 two spilled registers)
+    auto hp_now = [&]() {
+        int l = lr;
+        asm volatile("" : "+v"(l));
+        return (int)(((0x73261540u >> ((l >> 2) * 4)) & 7u) << 2) | (l & 3);   // 4-lane blocks 0..7 -> 0, 4, 5, 1, 6, 2, 3, 7 (branch-free)
+    };
     const int wc = wave & 1, wq = wave >> 1;   // cout fragment (32 rows) / pixel-row fragment group of this wave
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int pt = xcd * a.pt_per_xcd + slot;
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
         if (kt == 0) BN_STAMP(1);
         const char *Wt = smem + ((kt & 1) ? BN_C : BN_A), *Xt = smem + ((kt & 1) ? BN_B : BN_A + 8192);
         if constexpr (MODE == 2) {   // the downsample conv on the centre pixels (kt == 0 is the only chunk)
-            const int pc_ = 32 * wq + lr;
+            const int pc_ = 32 * wq + hp_now();
             const int rc = ((pc_ >> 4) + 1) * BN_HW + (pc_ & 15) + 1;   // halo row of this lane's centre pixel
             bn_bf16x8 fx[4];
 #pragma unroll
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
     bn_f32x16 acc2;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
-    const int pB = 32 * wq + lr;
+    const int pB = 32 * wq + hp_now();
     const int r0 = (pB >> 4) * BN_HW + (pB & 15);   // halo row of this lane's pixel for tap (0, 0)
     // a tap's eight fragments are requested together, then its four MFMAs run: one LDS round trip per tap (the other three waves of
     // the SIMD fill it); a second register set for cross-tap prefetch does not fit the 128-register budget of 4 waves per SIMD
@@ -345,7 +356,7 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
             bn_u32x2 pk;
             pk.x = bn_pk_relu(bn_pk_bf16(acc2[4 * g + 0] + bv2[g].x, acc2[4 * g + 1] + bv2[g].y));
             pk.y = bn_pk_relu(bn_pk_bf16(acc2[4 * g + 2] + bv2[g].z, acc2[4 * g + 3] + bv2[g].w));
-            *reinterpret_cast<bn_u32x2 *>(T2 + pB * BN_ROWB + (((4 * wc + g) ^ ((pB >> 1) & 7)) << 4) + 8 * lh) = pk;
+            *reinterpret_cast<bn_u32x2 *>(T2 + (32 * wq + lr) * BN_ROWB + (((4 * wc + g) ^ ((lr >> 1) & 7)) << 4) + 8 * lh) = pk;   // row = lane
         }
     }
     if constexpr (MODE == 2 && !M2_SLAB) {
@@ -367,6 +378,7 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
         // ---- phase C: y = relu(W3 . T2 + b3 + residual), 64 output channels at a time = 2 cout x 4 pixel fragments per quarter
         const float *bias3 = reinterpret_cast<const float *>(smem + BN_C);
         char *E = smem + BN_B;
+        const int pE = 32 * wq + hp_now();   // the pixel of accumulator column lr
         // the pixel operand (T2 fragments) is the same for all four quarters: read once; the weight fragments of quarter q + 1 are
         // requested before quarter q's epilogue (W3 is read-only in this phase: no hazard with the image barriers)
         bn_bf16x8 fbc[4], fac[2][4];
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
                     pk.x = bn_pk_relu(bn_pk_bf16(s0.x, s0.y));
                     pk.y = bn_pk_relu(bn_pk_bf16(s1.x, s1.y));
                 }
-                *reinterpret_cast<bn_u32x2 *>(E + pB * BN_ES + c_local * 2) = pk;
+                *reinterpret_cast<bn_u32x2 *>(E + pE * BN_ES + c_local * 2) = pk;
             }
             BN_BAR_RAW();   // raw barriers in this loop: __syncthreads() would wait for the previous quarter's stores to COMPLETE (vmcnt 0)
             if (q == 1) BN_STAMP(14);
@@ -453,7 +465,7 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
     #pragma unroll
         for (int q2 = 0; q2 < 2; ++q2) {
             const int q = 2 * wc + q2;   // output channels 64 q .. 64 q + 63
-            // bias (+ the fused downsample conv's value, ReLU) -> bf16, in accumulator layout: lane = pixel lr, 4 consecutive channels per group.
+            // bias (+ the fused downsample conv's value, ReLU) -> bf16, in accumulator layout: lane = pixel hp, 4 consecutive channels per group.
             // One 32-channel fragment at a time (its accumulator dies into 8 packed registers before the next starts: register budget 128)
             unsigned pkv[2][8];
     #pragma unroll
@@ -485,14 +497,15 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (q2 == 0) BN_STAMP(13);
+            const int hp = hp_now();
     #pragma unroll
-            for (int h = 0; h < 2; ++h) {   // pixels 16 h .. 16 h + 15 of the wave's 32: lanes lr >> 4 == h hold them
-                if ((lr >> 4) == h) {
+            for (int h = 0; h < 2; ++h) {   // pixels 16 h .. 16 h + 15 of the wave's 32: the lanes with hp >> 4 == h hold them
+                if ((hp >> 4) == h) {
     #pragma unroll
                     for (int f = 0; f < 2; ++f)
     #pragma unroll
                         for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<bn_u32x2 *>(slab + (lr & 15) * BN_ES + f * 64 + 16 * g + 8 * lh) = (bn_u32x2){pkv[f][2 * g], pkv[f][2 * g + 1]};
+                            *reinterpret_cast<bn_u32x2 *>(slab + (hp & 15) * BN_ES + f * 64 + 16 * g + 8 * lh) = (bn_u32x2){pkv[f][2 * g], pkv[f][2 * g + 1]};
                 }
                 // The slab is read back by OTHER lanes of the wave, in another vector type: without a compiler-level ordering point hipcc
                 // duplicated the read-out into the lanes that skip the write block and ran it FIRST (stale rows in exactly those lanes' pieces;

@@ -951,11 +951,16 @@ __global__ __launch_bounds__(256, CT == 64 ? 4 : 2) void conv3x3_halo_kernel(Con
     int fa_off[BK / 16];
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) fa_off[kk] = swz(wc * 64 + lr, kk * 2 + lh);
+    // lane -> pixel of a 32-pixel fragment (= two 16-pixel tile rows, 18 halo rows apart): ds_read_b128 is served in the lane groups
+    // {0-3, 12-15, 20-27} {4-11, 16-19, 28-31} (+32), 16 lanes x 16 B = all 64 banks per pass.  With pixel = lane a group straddles the two
+    // tile rows and two of its halo rows coincide mod 16 (a 2-way conflict on every tap: SQ_LDS_BANK_CONFLICT 1.3 x the LDS-busy cycles,
+    // tools/pmc_lds_survey.sh); this permutation gives each group one whole tile row = 16 consecutive halo rows
+    const int hp = (int)(((0x73261540u >> ((lr >> 2) * 4)) & 7u) << 2) | (lr & 3);   // 4-lane blocks 0..7 -> 0, 4, 5, 1, 6, 2, 3, 7
     // halo row of this lane's pixel for tap (0,0), per pixel fragment j
     int r0[FP];
 #pragma unroll
     for (int j = 0; j < FP; ++j) {
-        const int p = (wp * FP + j) * 32 + lr;
+        const int p = (wp * FP + j) * 32 + hp;
         r0[j] = (p >> 4) * HALO_W + (p & 15);
     }
 
@@ -1031,7 +1036,7 @@ __global__ __launch_bounds__(256, CT == 64 ? 4 : 2) void conv3x3_halo_kernel(Con
             const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + c_local);
 #pragma unroll
             for (int j = 0; j < FP; ++j) {
-                const int p_local = (wp * FP + j) * 32 + lr;
+                const int p_local = (wp * FP + j) * 32 + hp;
                 f32x2 s01 = (f32x2){acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]} + (f32x2){bv.x, bv.y};
                 f32x2 s23 = (f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bv.z, bv.w};
                 if (a.relu == 2) { s01.x = silu(s01.x); s01.y = silu(s01.y); s23.x = silu(s23.x); s23.y = silu(s23.y); }

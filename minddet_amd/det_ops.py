@@ -582,7 +582,8 @@ class PrefixStatus:
         self._t = {}
 
     def tensor(self, batch, device):
-        key = (int(batch), str(device))
+        # one flag tensor per (batch, device, HIP stream): two streams running parts of a batch (graphs.SplitForward) never share a row
+        key = (int(batch), str(device), torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0)
         if key not in self._t:
             self._t[key] = torch.zeros((batch,), dtype=torch.int32, device=device)
         return self._t[key]

@@ -28,6 +28,57 @@ FUSE_DUAL = os.environ.get("MD_FUSE_DUAL", "1") == "1"
 RPN_FUSED_HEAD = os.environ.get("MD_RPN_FUSED", "1") == "1"  # 0: two md_conv2d launches per level (A/B)
 
 
+class SplitForward:
+    """`model.forward` on the S equal parts of a batch, each part on its own HIP stream, outputs concatenated in input order.
+
+    Why: a layer's launch ends with a partly filled round of workgroups (Mask R-CNN's 32-image shard: 525 ping-pong tiles on 256 CUs = 2.05
+    rounds -> 3) and with completion skew; with two streams the other half's next launch fills those CUs.  Same kernels on the same images
+    -> bit-identical outputs (tests/test_split_forward_gpu.py).  Measured r03, same box, tools/two_stream_halves.py: Mask R-CNN R101 b32
+    26.50 -> 25.04 ms/step (-5.5 %), YOLOv8l b32 7.50 -> 7.28 (-2.9 %), Faster R-CNN R50 b120 56.74 -> 56.10 (-1.1 %); YOLOv5s b32 gets 60 %
+    SLOWER (its 1.8 ms step is host-enqueue-bound: twice the launches); 3 / 4 / 8 streams lose everywhere.  Opt-in per config: test_cfg.streams.
+    The lazily built constants of the graph (anchors, segment offsets) are created by one single-stream pass per part shape before two
+    streams read them."""
+
+    def __init__(self, model, streams=2):
+        self.model, self.n = model, int(streams)
+        self._streams = None
+        self._primed = set()
+
+    def __call__(self, images, **kw):
+        B = images.shape[0]
+        if self.n <= 1 or B < self.n or B % self.n or kw.get("return_aux"):
+            return self.model.forward(images, **kw)
+        dev = images.device
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.n)]
+        step = B // self.n
+        key = (step,) + tuple(images.shape[1:])
+        cur = torch.cuda.current_stream(dev)
+        if key not in self._primed:
+            self.model.forward(images[:step], **kw)
+            self._primed.add(key)
+        outs = []
+        for i, st in enumerate(self._streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(self.model.forward(images[i * step:(i + 1) * step], **kw))
+        for st in self._streams:
+            cur.wait_stream(st)
+        res = []
+        for k in range(len(outs[0])):
+            ts = [o[k] for o in outs]
+            for t in ts:
+                t.record_stream(cur)   # allocated on a part's stream, read (and later freed) on the caller's
+            res.append(torch.cat(ts, 0))
+        return tuple(res)
+
+
+def _split_forward_of(model, test_cfg):
+    """test_cfg.streams (default 1) -> model.streams and model.forward_split (== model.forward for one stream)"""
+    model.streams = int((test_cfg or {}).get("streams", 1))
+    model.forward_split = SplitForward(model, model.streams)
+
+
 class ParamInit:
     """Deterministic parameter source (numpy Generator, seed 7 by default)."""
 
@@ -422,6 +473,7 @@ class FasterRCNN:
         self.rpn_head = build_head(rpn_head)
         self.roi_head = build_roi_head(roi_head)
         self.test_cfg = test_cfg
+        _split_forward_of(self, test_cfg)
 
     def to(self, device):
         for m in (self.backbone, self.neck, self.rpn_head, self.roi_head):
@@ -631,6 +683,7 @@ class CenterNet:
     def __init__(self, depth=18, num_classes=80, head_conv=64, K=100, base_width=64, seed=7, train_cfg=None,
                  test_cfg=None, dcn=True):
         init = ParamInit(seed)
+        _split_forward_of(self, test_cfg)
         self.backbone = ResNet(depth, base_width=base_width, init=init)
         cin = self.backbone.out_channels[-1]
         self.neck = []
@@ -821,6 +874,7 @@ class YOLOv5:
     def __init__(self, depth_multiple=0.33, width_multiple=0.5, num_classes=80, conf_thres=0.25, iou_thres=0.45,
                  max_det=300, nms_pre=4096, seed=7, train_cfg=None, test_cfg=None):
         init = ParamInit(seed)
+        _split_forward_of(self, test_cfg)
         ch = lambda c: max(8, int(math.ceil(c * width_multiple / 8) * 8))
         d = lambda n: max(1, round(n * depth_multiple))
         c64, c128, c256, c512, c1024 = ch(64), ch(128), ch(256), ch(512), ch(1024)
@@ -978,6 +1032,7 @@ class YOLOv8:
     def __init__(self, depth_multiple=1.0, width_multiple=1.0, max_channels=512, num_classes=80, reg_max=16, conf_thres=0.25,
                  iou_thres=0.7, max_det=300, nms_pre=4096, seed=7, train_cfg=None, test_cfg=None):
         init = ParamInit(seed)
+        _split_forward_of(self, test_cfg)
         ch = lambda c: max(8, int(math.ceil(min(c, max_channels) * width_multiple / 8) * 8))
         d = lambda n: max(1, round(n * depth_multiple))
         c64, c128, c256, c512, c1024 = ch(64), ch(128), ch(256), ch(512), ch(1024)

@@ -1,0 +1,81 @@
+"""-m gpu: graphs.SplitForward (test_cfg.streams): the batch as equal parts on separate HIP streams must give exactly the single-stream
+outputs (same kernels on the same images: bit-identical), repeatedly, with the lazily built constants created race-free, for every detector
+family that carries it; the big-shard configs that enable it (Mask R-CNN R101-FPN, YOLOv8l) at their bench batch."""
+import pytest
+import torch
+
+from tests.conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs MI355X")]
+DEV = "cuda:0"
+
+
+def _images(n, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.zeros((n, h, w, 8))
+    x[..., :3] = torch.randn((n, h, w, 3), generator=g)
+    return x.to(torch.bfloat16).to(DEV)
+
+
+@pytest.mark.parametrize("cfgp,hw", [("configs/mask_rcnn/mask_rcnn_tiny.py", (128, 192)), ("configs/faster_rcnn/faster_rcnn_tiny.py", (128, 192)),
+                                     ("configs/yolov8/yolov8_tiny.py", (128, 160))])
+def test_split_forward_is_bit_identical_tiny(cfgp, hw):
+    from minddet.models import Config, build_detector
+    from minddet_amd.graphs import SplitForward
+
+    cfg = Config.fromfile(cfgp)
+    m = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(DEV)
+    assert m.streams == int((cfg.test_cfg or {}).get("streams", 1)) and m.forward_split.n == m.streams
+    x = _images(8, hw[0], hw[1], 11)
+    ref = m.forward(x)
+    torch.cuda.synchronize()
+    for parts in (2, 4):
+        sp = SplitForward(m, parts)          # the FIRST call builds the graph's lazy constants before the streams fork
+        for rep in range(3):
+            out = sp(x)
+            torch.cuda.synchronize()
+            assert len(out) == len(ref)
+            for a, b in zip(out, ref):
+                assert a.shape == b.shape and torch.equal(a, b), (cfgp, parts, rep)
+    # an indivisible batch / one stream falls back to the plain forward
+    out = SplitForward(m, 3)(x)
+    assert all(torch.equal(a, b) for a, b in zip(out, ref))
+    assert int(m.prefix_status.flagged()) >= 0
+
+
+def test_split_forward_mask_rcnn_r101_bench_shard():
+    """configs/mask_rcnn/mask_rcnn_r101_fpn.py enables two streams: at a 8-image batch (two 4-image halves) the outputs, pasted masks included,
+    equal the single-stream ones bit for bit"""
+    from minddet.models import Config, build_detector
+    from minddet_amd import nn_ops
+    from minddet_amd.data import synthetic_images
+
+    cfg = Config.fromfile("configs/mask_rcnn/mask_rcnn_r101_fpn.py")
+    m = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(DEV)
+    assert m.streams == 2
+    x = nn_ops.to_stem_layout(synthetic_images(8, 800, 1344, seed=20240317, device=DEV))
+    ref = m.forward(x, paste=True)
+    out = m.forward_split(x, paste=True)
+    out2 = m.forward_split(x, paste=True)
+    torch.cuda.synchronize()
+    assert len(out) == 4
+    for a, b, c in zip(out, ref, out2):
+        assert torch.equal(a, b) and torch.equal(c, b)
+
+
+def test_split_forward_yolov8l_bench_shard():
+    from minddet.models import Config, build_detector
+    from minddet_amd import nn_ops
+    from minddet_amd.data import synthetic_images
+
+    cfg = Config.fromfile("configs/yolov8/yolov8l.py")
+    m = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(DEV)
+    assert m.streams == 2
+    x = synthetic_images(32, 640, 640, seed=20240317, device=DEV)
+    if nn_ops.stem_layout_ok(640, 640) and getattr(m, "stem", None) is not None:
+        x = nn_ops.to_stem_layout(x)
+    ref = m.forward(x)
+    for _ in range(3):
+        out = m.forward_split(x)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(out, ref))

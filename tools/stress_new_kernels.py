@@ -1,4 +1,4 @@
-"""Race hunt: the persistent ping-pong form (variant 32), its HALO forms (36 / 37 / 38, the fused head with 34), the stream kernel (30), md_bottleneck
+"""Race hunt: the persistent ping-pong form (variant 32), its HALO forms (36 / 37 / 38, the fused head with 34), the halo-reuse kernel (27 / 11), the stream kernel (30), md_bottleneck
 and md_stem_conv run many times on the same operands;
 every output must equal the first one and the reference kernel's bit for bit.  python tools/stress_new_kernels.py [reps]"""
 import os, sys
@@ -15,7 +15,9 @@ CASES = [("pers 3x3 256 b30 P2", 32, 15, (30, 200, 336, 256), 256, 3, False), ("
          ("stream 256->1024 +res", 30, 20, (60, 50, 84, 256), 1024, 1, True), ("stream 512->256", 30, 20, (60, 100, 168, 512), 256, 1, False),
          ("stream 256->256 +res", 30, 20, (60, 100, 168, 256), 256, 1, True),
          ("halo mf1 3x3 256 b30 P2", 37, 22, (30, 200, 336, 256), 256, 3, False), ("halo mf0 3x3 256 @100x168 +res", 36, 15, (30, 100, 168, 256), 256, 3, True),
-         ("halo pers 3x3 256 b30 P2", 38, 22, (30, 200, 336, 256), 256, 3, False), ("halo mf1 3x3 128->512 @41x77", 37, 22, (16, 41, 77, 128), 512, 3, False)]
+         ("halo pers 3x3 256 b30 P2", 38, 22, (30, 200, 336, 256), 256, 3, False), ("halo mf1 3x3 128->512 @41x77", 37, 22, (16, 41, 77, 128), 512, 3, False),
+         ("halo64 3x3 64->64 @160x160", 27, 2, (16, 160, 160, 64), 64, 3, False), ("halo64 3x3 128->128 @80x80 +res", 27, 2, (32, 80, 80, 128), 128, 3, True),
+         ("halo128 3x3 128->128 @77x45", 11, 2, (8, 77, 45, 128), 128, 3, False)]
 for name, v, vref, xs, cout, k, res in CASES:
     cin = xs[3]
     w = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (k * k * cin)) ** 0.5
