@@ -428,10 +428,13 @@ def main(argv=None):
         u8 = torch.randint(0, 256, (B, H, W, 3), generator=g_u8, dtype=torch.uint8).to(dev)
         return u8, torch.tensor([1.0, 0, 0, 0, 1.0, 0], dtype=torch.float32, device=dev).repeat(B, 1).contiguous()
 
+    def pre_part(u8_, mat_):   # uint8 batch (or a part of it) -> the model's input layout
+        return nn_ops.image_preprocess(u8_, mat_, MEAN, STD, (H, W), stem_layout=images.shape[3] == 4)
+
     preprocess = None
     if args.from_uint8:
         images_u8, pre_mat = make_u8()
-        preprocess = lambda: nn_ops.image_preprocess(images_u8, pre_mat, MEAN, STD, (H, W), stem_layout=images.shape[3] == 4)  # noqa: E731
+        preprocess = lambda: (images_u8, pre_mat)  # noqa: E731   (the step's input is the uint8 batch: forward() pre-processes it)
 
     n_streams = args.streams if args.streams is not None else int(getattr(model, "streams", 1))
     if n_streams > 1 and (B % n_streams or not hasattr(model, "forward_split")):
@@ -446,9 +449,10 @@ def main(argv=None):
 
     def forward(x):
         bracket["idx"] = 0
+        from_u8_in = isinstance(x, tuple)           # (uint8 batch, affine matrices): md_image_preprocess is part of the step
         if splitter is not None and not serial["on"]:
-            return splitter(x)
-        return model.forward(x)
+            return splitter(x, prepare=pre_part if from_u8_in else None)   # each part pre-processed on its own stream
+        return model.forward(pre_part(*x) if from_u8_in else x)
 
     def gatherer(out):   # Mask R-CNN: the 28x28 masks travel as fp16 in a second fixed-shape all_gather
         return gather_detections_async(out[0], out[1], masks=out[2] if len(out) > 2 else None, force=True)
@@ -525,8 +529,7 @@ def main(argv=None):
     from_u8 = None
     if not args.from_uint8 and not args.no_from_uint8 and not args.graph and rank == 0 and not use_dist and hasattr(nn_ops, "image_preprocess"):
         u8, mat = make_u8()
-        pre2 = lambda: nn_ops.image_preprocess(u8, mat, MEAN, STD, (H, W), stem_layout=images.shape[3] == 4)  # noqa: E731
-        step2, finish2 = make_step(forward, images, False, None, pre2)
+        step2, finish2 = make_step(forward, images, False, None, lambda: (u8, mat))
         k2 = max(2, min(args.steps, 5))
         dt2 = run_timed(step2, finish2, k2, 1, False, torch.cuda.synchronize, None, None)
         from_u8 = {"ms_per_step": round(dt2 / k2 * 1e3, 3), "value": round(B * k2 / dt2, 2), "steps": k2,

@@ -44,24 +44,32 @@ class SplitForward:
         self._streams = None
         self._primed = set()
 
-    def __call__(self, images, **kw):
-        B = images.shape[0]
+    def __call__(self, images, prepare=None, **kw):
+        """images: the batch -- or, with `prepare`, a tuple of batch-first tensors that `prepare(*part)` turns into a part's input batch ON the
+        part's stream (pre-processing from uint8: otherwise that launch would sit alone on the caller's stream between two joins)"""
+        ins = images if isinstance(images, (tuple, list)) else (images,)
+        B = ins[0].shape[0]
         if self.n <= 1 or B < self.n or B % self.n or kw.get("return_aux"):
-            return self.model.forward(images, **kw)
-        dev = images.device
+            return self.model.forward(images if prepare is None else prepare(*ins), **kw)
+        dev = ins[0].device
         if self._streams is None:
             self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.n)]
         step = B // self.n
-        key = (step,) + tuple(images.shape[1:])
+
+        def part(i):
+            p = [t[i * step:(i + 1) * step] for t in ins]
+            return p[0] if prepare is None else prepare(*p)
+
         cur = torch.cuda.current_stream(dev)
+        key = (step, prepare is not None) + tuple(ins[0].shape[1:])
         if key not in self._primed:
-            self.model.forward(images[:step], **kw)
+            self.model.forward(part(0), **kw)
             self._primed.add(key)
         outs = []
         for i, st in enumerate(self._streams):
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                outs.append(self.model.forward(images[i * step:(i + 1) * step], **kw))
+                outs.append(self.model.forward(part(i), **kw))
         for st in self._streams:
             cur.wait_stream(st)
         res = []

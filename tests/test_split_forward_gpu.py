@@ -37,10 +37,16 @@ def test_split_forward_is_bit_identical_tiny(cfgp, hw):
             assert len(out) == len(ref)
             for a, b in zip(out, ref):
                 assert a.shape == b.shape and torch.equal(a, b), (cfgp, parts, rep)
+    # the parts' inputs made ON the parts' streams from batch-first tensors (bench.py: md_image_preprocess of a uint8 part)
+    scale = torch.full((8, 1, 1, 1), 2.0, dtype=torch.bfloat16, device=DEV)
+    out = SplitForward(m, 2)((x * 0.5, scale), prepare=lambda a, b: a * b)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(out, ref))
     # an indivisible batch / one stream falls back to the plain forward
     out = SplitForward(m, 3)(x)
     assert all(torch.equal(a, b) for a, b in zip(out, ref))
-    assert int(m.prefix_status.flagged()) >= 0
+    # the sticky pre-NMS prefix flags live in one tensor per (batch, device, stream): the parts' streams never share a row
+    assert len({k[2] for k in m.prefix_status._t}) >= 3
 
 
 def test_split_forward_mask_rcnn_r101_bench_shard():

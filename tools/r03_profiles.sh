@@ -14,13 +14,22 @@ run_cfg() {  # name config batch [extra bench args]
 }
 echo "== PMC traffic first (bench.py reports it only when the file matches the kernel sources)"
 bash tools/pmc_conv_traffic.sh $OUT/frcnn_conv_traffic.json 120 && cp $OUT/frcnn_conv_traffic.json profiles/r03_conv_traffic.json
+bash tools/pmc_conv_traffic.sh $OUT/yolov5s_conv_traffic.json 32 --config configs/yolov5/yolov5s.py && cp $OUT/yolov5s_conv_traffic.json profiles/r03_yolov5s_conv_traffic.json
+bash tools/pmc_conv_traffic.sh $OUT/yolov8l_conv_traffic.json 32 --config configs/yolov8/yolov8l.py --streams 1 && cp $OUT/yolov8l_conv_traffic.json profiles/r03_yolov8l_conv_traffic.json
 echo "== default bench line"
 python bench.py --steps 20 --warmup 5 > $OUT/frcnn_bench.json 2> $OUT/frcnn_bench.err
 tail -c 1200 $OUT/frcnn_bench.json; echo
 run_cfg frcnn_all configs/faster_rcnn/faster_rcnn_r50_fpn.py 120
 run_cfg yolov5s configs/yolov5/yolov5s.py 32
-run_cfg yolov8l configs/yolov8/yolov8l.py 32
-run_cfg maskrcnn configs/mask_rcnn/mask_rcnn_r101_fpn.py 32 --paste-masks
+# the configs that run two HIP streams (test_cfg.streams = 2): the per-layer table comes from a one-stream run (--bracket all needs it), the bench line
+# from the config as it ships
+run_cfg yolov8l_one_stream configs/yolov8/yolov8l.py 32 --streams 1
+run_cfg maskrcnn_one_stream configs/mask_rcnn/mask_rcnn_r101_fpn.py 32 --paste-masks --streams 1
+mv $OUT/yolov8l_one_stream_conv_layers.json $OUT/yolov8l_conv_layers.json
+mv $OUT/maskrcnn_one_stream_conv_layers.json $OUT/maskrcnn_conv_layers.json
+python bench.py --config configs/yolov8/yolov8l.py --batch 32 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/yolov8l_bench.json 2> $OUT/yolov8l_bench.err
+python bench.py --config configs/mask_rcnn/mask_rcnn_r101_fpn.py --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --paste-masks > $OUT/maskrcnn_bench.json 2> $OUT/maskrcnn_bench.err
+tail -c 300 $OUT/yolov8l_bench.json; echo; tail -c 300 $OUT/maskrcnn_bench.json; echo
 for c in "frcnn configs/faster_rcnn/faster_rcnn_r50_fpn.py 120" "yolov5s configs/yolov5/yolov5s.py 32" "yolov8l configs/yolov8/yolov8l.py 32"; do
   set -- $c
   (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_$1 -- python3 $ROOT/bench.py --config $ROOT/$2 --batch $3 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-zero-operands --no-from-uint8 > $ROOT/$OUT/prof_$1.log 2>&1)
@@ -29,5 +38,3 @@ for c in "frcnn configs/faster_rcnn/faster_rcnn_r50_fpn.py 120" "yolov5s configs
   rm -rf $OUT/prof_$1
   head -8 $OUT/$1_kernel_stats.csv | cut -c1-200
 done
-bash tools/pmc_conv_traffic.sh $OUT/yolov5s_conv_traffic.json 32 --config configs/yolov5/yolov5s.py
-bash tools/pmc_conv_traffic.sh $OUT/yolov8l_conv_traffic.json 32 --config configs/yolov8/yolov8l.py
