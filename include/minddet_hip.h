@@ -137,7 +137,8 @@ typedef struct md_conv_tune {
     int32_t stream_rounds;     /* conv1x1_stream_kernel: workgroup rounds the pixel range is cut into; 0 = default 1 */
     int32_t stream_wgs_per_cu; /* conv1x1_stream_kernel: workgroups per CU the grid is sized for; 0 = default 2 */
     int32_t stream_cache_bits; /* conv1x1_stream_kernel cache policy: 0 = default (6); else 8 | bits (1 = activation DMA nt,
-                                  2 = residual DMA nt, 4 = stores nt) */
+                                  2 = residual DMA nt, 4 = stores nt); | 16 = the K = 512 form on 128-cout (4-wave) workgroups also
+                                  where the 256-cout (8-wave) form applies (A/B) */
     int32_t pers_min_k;        /* the persistent form of the ping-pong kernel is the dispatcher's choice for eligible layers with
                                   K >= this; 0 = default 2304 */
     int32_t dual_pp_min_k;     /* md_conv1x1_dual runs on the ping-pong kernel when its concatenated K is >= this (and Cout % 256 == 0,

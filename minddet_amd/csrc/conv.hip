@@ -139,10 +139,12 @@ static thread_local long long g_launch_count = 0;
 struct Tune {
     long long chunk_limit;   // activation bytes above which the batch is sliced into image chunks (the kernels' 32-bit DMA offsets)
     int stream_rounds, stream_wgs_per_cu, stream_cache_bits, pers_min_k, dual_pp_min_k;
+    bool stream_narrow;      // stream_cache_bits & 16: the K = 512 form on 4-wave (128-cout) workgroups also where the 8-wave form applies (A/B)
 };
 static Tune resolve_tune(const md_conv_tune *t) {
-    Tune r = {0x7fff0000LL, 1, 2, 6, 2304, 768};
+    Tune r = {0x7fff0000LL, 1, 2, 6, 2304, 768, false};
     if (!t) return r;
+    r.stream_narrow = (t->stream_cache_bits & 16) != 0;
     if (t->chunk_limit > 0 && t->chunk_limit < 0x7fff0000) r.chunk_limit = t->chunk_limit;
     if (t->stream_rounds >= 1 && t->stream_rounds <= 64) r.stream_rounds = t->stream_rounds;
     if (t->stream_wgs_per_cu >= 1 && t->stream_wgs_per_cu <= 8) r.stream_wgs_per_cu = t->stream_wgs_per_cu;
@@ -608,13 +610,16 @@ static int launch_conv_dual(ConvArgs &a, hipStream_t s, const Tune &tn) {
 
 // RES 0: no residual; 1: residual with the output's layout (or a channel slice, a.Rs); 2: residual [N, ceil(Ho/2), ceil(Wo/2), Cout] read with
 // nearest 2x upsampling (a.res_up: the FPN top-down add fused into the lateral conv)
-template <int K, int CB, bool SILU, int RES>
-__global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int tpw, int n_chunks, int chunks_per_xcd) {
+// NW = waves per workgroup (cout tile = NW * CB * 32).  8 for K = 512 with Cout % 256 == 0 (r03): with 4 waves (CB = 1: 128 couts) every activation
+// tile was staged by Cout / 128 workgroups, and PMC showed the second reader of a 256-cout layer missing L2 for half of it (FETCH 1.46 x the
+// activation bytes, launch 1.35-1.53 x algorithmic); one 8-wave workgroup stages the tile once for 256 couts, same waves and LDS per CU.
+template <int K, int CB, bool SILU, int RES, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void conv1x1_stream_kernel(ConvArgs a, int tpw, int n_chunks, int chunks_per_xcd) {
     typedef __attribute__((address_space(3))) void lds_void;
     constexpr int KS = K / 16, RB = K * 2;          // MFMA k-steps, bytes per activation row
     constexpr int PT = 32, SLOT = PT * RB;          // pixels per tile, bytes per ring slot
-    constexpr int NR = K == 512 ? 2 : (K == 128 ? 4 : 3), D = NR - 1;   // ring slots, tiles of look-ahead
-    constexpr int ND = SLOT / 4096;                 // x DMA instructions per wave and tile (1 KiB each)
+    constexpr int NR = K == 512 ? (NW == 8 ? 3 : 2) : (K == 128 ? 4 : 3), D = NR - 1;   // ring slots, tiles of look-ahead (one 8-wave workgroup per CU: 3)
+    constexpr int ND = SLOT / (NW * 1024);          // x DMA instructions per wave and tile (1 KiB each)
     constexpr int RPI = RB >= 1024 ? 1 : 1024 / RB; // tile rows per DMA instruction
     constexpr int CW = CB * 32;                     // couts per wave (4 waves: CT = 4 * CW)
     constexpr int CPP = CB * 4, EROW = CPP * 16;    // 16-B chunks / bytes per row of the wave's epilogue image [32 px][CW]
@@ -623,13 +628,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
     constexpr int ESH = CPP == 8 ? 1 : 2;           // image swizzle: chunk ^= (row >> ESH) & (CPP - 1)
     constexpr int NRES = RES != 0 ? NE : 0;
     static_assert(K % 128 == 0 && K <= 512 && CB * K <= 512, "weights must fit 128 registers per lane");
+    static_assert(ND >= 1 && ND * NW * 1024 == SLOT, "the x tile must split into whole 1-KiB pieces per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *ring = smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
     char *E = smem + NR * SLOT + wave * EW;
-    float *bias_lds = reinterpret_cast<float *>(smem + NR * SLOT + 4 * EW);
+    float *bias_lds = reinterpret_cast<float *>(smem + NR * SLOT + NW * EW);
 
     const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
     const int ct = slot_id % a.n_ctiles, chunk = xcd * chunks_per_xcd + slot_id / a.n_ctiles;
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
     const int t0 = chunk * tpw;
     const int nt = a.n_ptiles - t0 < tpw ? a.n_ptiles - t0 : tpw;
     if (nt <= 0) return;
-    const int cout_w = ct * (4 * CW) + wave * CW;   // this wave's first output channel
+    const int cout_w = ct * (NW * CW) + wave * CW;  // this wave's first output channel
     const int r_stride = a.Rs ? a.Rs : a.Ctot;      // residual pixel stride (channels)
     const int r_c0 = a.Rs ? cout_w : a.c_off + cout_w;
     const int y_c0 = a.c_off + cout_w;
@@ -738,7 +744,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
 #pragma unroll
     for (int t = 0; t < D; ++t) dma_x(t, t);
     if constexpr (RES != 0) dma_res(0);
-    if (tid < 4 * CW) bias_lds[tid] = a.bias[ct * (4 * CW) + tid];
+    if (tid < NW * CW) bias_lds[tid] = a.bias[ct * (NW * CW) + tid];
     bf16x8 wr[CB][KS];
 #pragma unroll
     for (int b = 0; b < CB; ++b)
@@ -824,14 +830,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
 
 // dispatch + launch of conv1x1_stream_kernel; MD_ERR_UNSUPPORTED_STREAM when the layer is not one it takes
 #define MD_ERR_UNSUPPORTED_STREAM 101
-template <int K, int CB>
+template <int K, int CB, int NW = 4>
 static int launch_conv1x1_stream_t(ConvArgs &a, hipStream_t s, const Tune &tn) {
-    constexpr int NR = K == 512 ? 2 : (K == 128 ? 4 : 3);
-    constexpr int CT = 4 * CB * 32;
-    const int lds = NR * 32 * K * 2 + 4 * (32 * CB * 64) + CT * 4;
+    constexpr int NR = K == 512 ? (NW == 8 ? 3 : 2) : (K == 128 ? 4 : 3);
+    constexpr int CT = NW * CB * 32;
+    const int lds = NR * 32 * K * 2 + NW * (32 * CB * 64) + CT * 4;
     a.n_ctiles = a.Cout / CT;
     a.n_ptiles = (a.M + 31) / 32;
-    const long long slots = 256LL * tn.stream_wgs_per_cu * tn.stream_rounds;      // resident workgroups (two per CU) x rounds
+    const long long slots = 256LL * tn.stream_wgs_per_cu * 4 / NW * tn.stream_rounds;   // resident workgroups (two 4-wave ones per CU) x rounds
     a.tune = tn.stream_cache_bits;
     long long tpw = ((long long)a.n_ptiles * a.n_ctiles + slots - 1) / slots;
     if (tpw < 4) tpw = 4;
@@ -839,13 +845,13 @@ static int launch_conv1x1_stream_t(ConvArgs &a, hipStream_t s, const Tune &tn) {
     const long long chunks_per_xcd = (n_chunks + 7) / 8;
     const long long blocks = chunks_per_xcd * 8 * a.n_ctiles;
     if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
-    auto k = a.res ? (a.relu == 2 ? conv1x1_stream_kernel<K, CB, true, 1> : conv1x1_stream_kernel<K, CB, false, 1>)
-                   : (a.relu == 2 ? conv1x1_stream_kernel<K, CB, true, 0> : conv1x1_stream_kernel<K, CB, false, 0>);
-    if (a.res_up) k = conv1x1_stream_kernel<K, CB, false, 2>;
+    auto k = a.res ? (a.relu == 2 ? conv1x1_stream_kernel<K, CB, true, 1, NW> : conv1x1_stream_kernel<K, CB, false, 1, NW>)
+                   : (a.relu == 2 ? conv1x1_stream_kernel<K, CB, true, 0, NW> : conv1x1_stream_kernel<K, CB, false, 0, NW>);
+    if (a.res_up) k = conv1x1_stream_kernel<K, CB, false, 2, NW>;
     if (ensure_dyn_lds((const void *)k, lds) != MD_OK) return MD_ERR_HIP;
     ++g_launch_count;
     g_last_kernel = MD_CONV_KERNEL_STREAM_1X1;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, a, (int)tpw, (int)n_chunks, (int)chunks_per_xcd);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), lds, s, a, (int)tpw, (int)n_chunks, (int)chunks_per_xcd);
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
@@ -863,6 +869,8 @@ static int launch_conv1x1_stream(ConvArgs &a, hipStream_t s, const Tune &tn) {
     const bool wide = a.Cout % 256 == 0;
     if (a.Cin == 128) return wide ? launch_conv1x1_stream_t<128, 2>(a, s, tn) : launch_conv1x1_stream_t<128, 1>(a, s, tn);
     if (a.Cin == 256) return wide ? launch_conv1x1_stream_t<256, 2>(a, s, tn) : launch_conv1x1_stream_t<256, 1>(a, s, tn);
+    // K = 512: 256 couts per (8-wave) workgroup where Cout allows, so that an activation tile is staged once per 256 couts
+    if (wide && !tn.stream_narrow) return launch_conv1x1_stream_t<512, 1, 8>(a, s, tn);
     return launch_conv1x1_stream_t<512, 1>(a, s, tn);
 }
 

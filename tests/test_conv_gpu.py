@@ -578,9 +578,10 @@ def test_conv1x1_stream_kernel_many_tiles_per_workgroup_and_rounds():
         r = torch.randn((6, 100, 167, Cout), generator=g).to(torch.bfloat16).to(DEV)
         ref = nn_ops.conv2d(x, pc, residual=r, variant=20)
         for rounds in (1, 3):
-            got = nn_ops.conv2d(x, pc, residual=r, variant=30, tune=nn_ops.ConvTune(stream_rounds=rounds))
-            assert lib.md_conv2d_last_kernel() == 8
-            assert torch.equal(got, ref), (Cin, Cout, rounds)
+            for bits in (0, 16):     # 16: the K = 512 layer on 4-wave workgroups
+                got = nn_ops.conv2d(x, pc, residual=r, variant=30, tune=nn_ops.ConvTune(stream_rounds=rounds, stream_cache_bits=bits))
+                assert lib.md_conv2d_last_kernel() == 8
+                assert torch.equal(got, ref), (Cin, Cout, rounds, bits)
     # not pointwise / K = 64 / Cout not a multiple of 128: variant 30 is the dispatcher's own choice
     for (Cin, Cout, k) in ((64, 256, 1), (256, 64, 1), (128, 128, 3)):
         wt = torch.randn((Cout, Cin, k, k), generator=g) * 0.05
@@ -617,6 +618,9 @@ def test_conv1x1_stream_kernel_random_shapes_against_the_tile_kernel():
         got = nn_ops.conv2d(x, pc, residual=r, res_upsample=kind == 2, variant=30, tune=nn_ops.ConvTune(stream_rounds=rounds))
         assert lib.md_conv2d_last_kernel() == 8, (case, cin, cout)
         assert torch.equal(got, ref), (case, cin, cout, n, h, w, kind, act, rounds)
+        if cin == 512:   # K = 512 runs 256 couts per 8-wave workgroup where Cout % 256 == 0 (r03); the 128-cout 4-wave form stays reachable per call
+            got4 = nn_ops.conv2d(x, pc, residual=r, res_upsample=kind == 2, variant=30, tune=nn_ops.ConvTune(stream_rounds=rounds, stream_cache_bits=16))
+            assert lib.md_conv2d_last_kernel() == 8 and torch.equal(got4, ref), (case, cin, cout, "4-wave form")
 
 
 @pytest.mark.parametrize("cfg", [

@@ -13,7 +13,7 @@ bad = 0
 CASES = [("pers 3x3 256 b30 P2", 32, 15, (30, 200, 336, 256), 256, 3, False), ("pers 3x3 256 @50x84", 32, 15, (60, 50, 84, 256), 256, 3, False),
          ("pers 3x3 512 @25x42", 32, 15, (60, 25, 42, 512), 512, 3, False), ("pers 1x1 1024->256", 32, 15, (60, 50, 84, 1024), 256, 1, False),
          ("stream 256->1024 +res", 30, 20, (60, 50, 84, 256), 1024, 1, True), ("stream 512->256", 30, 20, (60, 100, 168, 512), 256, 1, False),
-         ("stream 256->256 +res", 30, 20, (60, 100, 168, 256), 256, 1, True),
+         ("stream 256->256 +res", 30, 20, (60, 100, 168, 256), 256, 1, True), ("stream 8-wave 512->2048 +res", 30, 20, (60, 25, 42, 512), 2048, 1, True),
          ("halo mf1 3x3 256 b30 P2", 37, 22, (30, 200, 336, 256), 256, 3, False), ("halo mf0 3x3 256 @100x168 +res", 36, 15, (30, 100, 168, 256), 256, 3, True),
          ("halo pers 3x3 256 b30 P2", 38, 22, (30, 200, 336, 256), 256, 3, False), ("halo mf1 3x3 128->512 @41x77", 37, 22, (16, 41, 77, 128), 512, 3, False),
          ("halo64 3x3 64->64 @160x160", 27, 2, (16, 160, 160, 64), 64, 3, False), ("halo64 3x3 128->128 @80x80 +res", 27, 2, (32, 80, 80, 128), 128, 3, True),
