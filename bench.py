@@ -537,6 +537,21 @@ def main(argv=None):
                            "layout) inside the timed region"}
         del u8, mat
 
+    # the same steps with the batch as two halves on two HIP streams (graphs.SplitForward), when the config runs on one: a secondary figure --
+    # `value` stays the one-stream run whose launches the roofline block brackets
+    two_streams = None
+    if (splitter is None and n_streams == 1 and B % 2 == 0 and hasattr(model, "forward_split") and rank == 0 and not use_dist and not args.graph
+            and not args.no_from_uint8 and images_u8 is None):
+        from minddet_amd.graphs import SplitForward
+
+        sp2 = SplitForward(model, 2)
+        step3, finish3 = make_step(lambda xx: sp2(xx), images, False, None, None)
+        k3 = max(2, min(args.steps, 10))
+        dt3 = run_timed(step3, finish3, k3, 2, False, torch.cuda.synchronize, None, None)
+        two_streams = {"ms_per_step": round(dt3 / k3 * 1e3, 3), "value": round(B * k3 / dt3, 2), "steps": k3,
+                       "what": "the same step with the batch as two halves on two HIP streams (test_cfg.streams = 2 would make it the default): "
+                               "bit-identical outputs, the other half's launches fill each launch's last partial round of workgroups"}
+
     roofline = None
     if instrument and records:
         # whole conv/FC set: every launch of the timed region (--bracket all) or of the fully bracketed last warmup step
@@ -740,7 +755,7 @@ def main(argv=None):
             "config": {"workload": wl, "batch_per_gpu": B, "streams": n_streams,
                        "global_batch": world * B, "parallelism": f"dp{world} (image sharding + all_gather of detections)",
                        "gmac_per_image": None if gmac is None else round(gmac, 2), "weights": "random init, seed 7"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "from_uint8": from_u8, "mask_paste": mask_paste,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "from_uint8": from_u8, "two_streams": two_streams, "mask_paste": mask_paste,
             # images (over every step of this run) whose class-wise NMS saw a FULL top-nms_pre prefix and fewer than max_det
             # survivors: only those can differ from the NMS over every candidate (DESIGN.md "pre-NMS prefix"); read after timing
             "nms_prefix": None if not hasattr(model, "prefix_status") else {
