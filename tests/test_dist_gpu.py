@@ -69,6 +69,19 @@ def test_bench_spawn_launcher_one_rank():
     assert j["config"]["parallelism"].startswith("dp1")
 
 
+def test_bench_spawn_launcher_one_rank_two_streams_two_gathers():
+    """the same launcher path with graphs.SplitForward inside the rank (--streams 2) on the Mask R-CNN graph: the two halves are joined on the
+    rank's compute stream before the two asynchronous all_gathers (detections; fp16 masks) are issued over RCCL"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--steps", "3", "--warmup", "1", "--batch", "4", "--streams", "2",
+           "--config", os.path.join(ROOT, "configs", "mask_rcnn", "mask_rcnn_tiny.py"), "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["config"]["streams"] == 2 and j["value"] > 0
+    assert "serialized single-stream pass" in j["roofline"]["bracketed"] and j["roofline"]["frac"] > 0
+
+
 def test_bench_refuses_more_ranks_than_devices():
     import torch
 
