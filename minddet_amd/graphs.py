@@ -52,8 +52,9 @@ class SplitForward:
         if self.n <= 1 or B < self.n or B % self.n or kw.get("return_aux"):
             return self.model.forward(images if prepare is None else prepare(*ins), **kw)
         dev = ins[0].device
-        if self._streams is None:
+        if self._streams is None or self._streams[0].device != dev:   # (a model moved to another GPU gets streams, and a priming pass, there)
             self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.n)]
+            self._primed = set()
         step = B // self.n
 
         def part(i):
