@@ -31,6 +31,13 @@ st = stamps.cpu().tolist()
 names = ["first chunk landed", "phase A loop done", "T1 written + taps 0-4 landed", "taps 0-4 multiplied", "taps 5-8 landed", "taps 5-8 multiplied",
          "T2 written + W3 landed", "quarter 0", "quarter 1", "quarter 2", "quarter 3", "stores drained"]
 print(f"{B}x{H}x{W}x{Cin}: workgroup lifetime {st[12] - st[0]} cycles")
-for i, n_ in enumerate(names):
-    print(f"  {n_:30s} {st[i + 1] - st[i]:7d}")
-print(f"  quarter 1 in detail: MFMAs {st[13] - st[8]}, image write + barrier {st[14] - st[13]}, residual add + store issue {st[15] - st[14]}, barrier {st[9] - st[15]}")
+if st[10] == 0:   # the barrier-free phase C of the identity / residual-tensor blocks (r03): two quarter PAIRS per wave, stamps 8 and 9 only
+    names = names[:7] + ["quarters 2wc (wave-private slab)", "quarters 2wc + 1"]
+    for i, n_ in enumerate(names):
+        print(f"  {n_:34s} {st[i + 1] - st[i]:7d}")
+    print(f"  {'stores drained':34s} {st[12] - st[9]:7d}")
+    print(f"  first quarter in detail: MFMAs + bias/pack {st[13] - st[7]}, slab write / read-out / residual add / stores {st[8] - st[13]}")
+else:
+    for i, n_ in enumerate(names):
+        print(f"  {n_:34s} {st[i + 1] - st[i]:7d}")
+    print(f"  quarter 1 in detail: MFMAs {st[13] - st[8]}, image write + barrier {st[14] - st[13]}, residual add + store issue {st[15] - st[14]}, barrier {st[9] - st[15]}")
