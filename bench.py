@@ -585,7 +585,8 @@ def main(argv=None):
         traffic = all_traffic = None
         traffic_note = "no PMC file for this library build"
         tp = os.path.join(ROOT, "profiles", {"FasterRCNN": "r03_conv_traffic.json", "YOLOv5": "r03_yolov5s_conv_traffic.json",
-                                             "YOLOv8": "r03_yolov8l_conv_traffic.json"}.get(type(model).__name__, "r03_conv_traffic.json"))
+                                             "YOLOv8": "r03_yolov8l_conv_traffic.json",
+                                             "MaskRCNN": "r03_maskrcnn_conv_traffic.json"}.get(type(model).__name__, "r03_conv_traffic.json"))
         PMC_PREFIX = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<256, 2, 2, 2, 2, 2,", 3: "conv_igemm_kernel<256, 1, 4,", 5: "conv3x3_halo_kernel",
                       7: "bottleneck64_kernel", 8: "conv1x1_stream_kernel"}  # all instantiations of the kernel
         if os.path.exists(tp):  # PMC passes are separate rocprofv3 runs (tools/pmc_traffic.py); same config only
@@ -595,7 +596,7 @@ def main(argv=None):
             same_build = tj.get("kernel_source_sha256") == kernel_source_hash()
             traffic_note = (f"rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{os.path.basename(tp)}" if same_build else
                             f"profiles/{os.path.basename(tp)} was measured on other kernel sources: not reported")
-            if same_build and tj.get("batch_per_gpu") == B and type(model).__name__ in ("FasterRCNN", "YOLOv5", "YOLOv8"):
+            if same_build and tj.get("batch_per_gpu") == B and type(model).__name__ in ("FasterRCNN", "YOLOv5", "YOLOv8", "MaskRCNN"):
                 all_traffic = round(tj["hbm_bytes_per_launch"] / 1e6, 2)
                 pmc_rows = [v for k_, v in tj.get("by_kernel", {}).items() if dom in PMC_PREFIX and k_.startswith(PMC_PREFIX[dom])]
                 if pmc_rows:

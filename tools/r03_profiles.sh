@@ -16,6 +16,7 @@ echo "== PMC traffic first (bench.py reports it only when the file matches the k
 bash tools/pmc_conv_traffic.sh $OUT/frcnn_conv_traffic.json 120 && cp $OUT/frcnn_conv_traffic.json profiles/r03_conv_traffic.json
 bash tools/pmc_conv_traffic.sh $OUT/yolov5s_conv_traffic.json 32 --config configs/yolov5/yolov5s.py && cp $OUT/yolov5s_conv_traffic.json profiles/r03_yolov5s_conv_traffic.json
 bash tools/pmc_conv_traffic.sh $OUT/yolov8l_conv_traffic.json 32 --config configs/yolov8/yolov8l.py --streams 1 && cp $OUT/yolov8l_conv_traffic.json profiles/r03_yolov8l_conv_traffic.json
+bash tools/pmc_conv_traffic.sh $OUT/maskrcnn_conv_traffic.json 32 --config configs/mask_rcnn/mask_rcnn_r101_fpn.py --streams 1 && cp $OUT/maskrcnn_conv_traffic.json profiles/r03_maskrcnn_conv_traffic.json
 echo "== default bench line"
 python bench.py --steps 20 --warmup 5 > $OUT/frcnn_bench.json 2> $OUT/frcnn_bench.err
 tail -c 1200 $OUT/frcnn_bench.json; echo
