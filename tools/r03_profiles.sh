@@ -31,9 +31,10 @@ mv $OUT/maskrcnn_one_stream_conv_layers.json $OUT/maskrcnn_conv_layers.json
 python bench.py --config configs/yolov8/yolov8l.py --batch 32 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/yolov8l_bench.json 2> $OUT/yolov8l_bench.err
 python bench.py --config configs/mask_rcnn/mask_rcnn_r101_fpn.py --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --paste-masks > $OUT/maskrcnn_bench.json 2> $OUT/maskrcnn_bench.err
 tail -c 300 $OUT/yolov8l_bench.json; echo; tail -c 300 $OUT/maskrcnn_bench.json; echo
+# (kernel stats on ONE stream: they are what the roofline block's per-launch figures must agree with; a two-stream config's roofline pass is the one-stream pass)
 for c in "frcnn configs/faster_rcnn/faster_rcnn_r50_fpn.py 120" "yolov5s configs/yolov5/yolov5s.py 32" "yolov8l configs/yolov8/yolov8l.py 32"; do
   set -- $c
-  (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_$1 -- python3 $ROOT/bench.py --config $ROOT/$2 --batch $3 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-zero-operands --no-from-uint8 > $ROOT/$OUT/prof_$1.log 2>&1)
+  (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_$1 -- python3 $ROOT/bench.py --config $ROOT/$2 --batch $3 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-zero-operands --no-from-uint8 --streams 1 > $ROOT/$OUT/prof_$1.log 2>&1)
   f=$(ls $OUT/prof_$1/*/*kernel_stats.csv | head -1)
   cp $f $OUT/$1_kernel_stats.csv
   rm -rf $OUT/prof_$1
