@@ -14,8 +14,10 @@
  *
  * Conventions (all ops):
  *   - params[] = inputs, then outputs, in the order documented per op; an OPTIONAL trailing
- *     workspace buffer (dtype "uint8") may follow the outputs -- when absent the op takes
- *     stream-ordered scratch (hipMallocAsync/hipFreeAsync on `stream`).
+ *     workspace buffer (dtype "uint8") may follow the outputs -- when absent the op uses the
+ *     library's scratch pool: ONE buffer per (device, stream), grown on demand and reused by
+ *     every later call on that stream (no driver call in the steady state; md_scratch_release
+ *     frees it).
  *   - every pointer in params[] is DEVICE memory owned by the caller; outputs are fixed
  *     shape and padded (keep[N] has `num` valid leading entries, the rest 0 --
  *     iou-bev-nms-org.cpp:247-249,274-281).
@@ -29,10 +31,10 @@
  *   - return 0 on success; non-zero on failure (iou-bev-nms-org.cpp:238,282): 1 = wrong
  *     nparam, 2 = bad dtype/shape, 3 = HIP runtime error, 4 = unsupported size.  No
  *     exceptions, no stdout, no exit().
- *   - re-entrant, no global mutable state; safe to call from several host threads on
- *     different streams.  (The only process-lifetime data are per-thread diagnostics counters --
- *     md_conv2d_last_kernel / md_conv2d_launch_count -- and a write-once "LDS size attribute set"
- *     cache per kernel and device.  Every tuning knob is a PER-CALL attribute: md_conv_tune.)
+ *   - re-entrant; safe to call from several host threads on different streams.  Process-lifetime
+ *     data: per-thread diagnostics counters (md_conv2d_last_kernel / md_conv2d_launch_count), a
+ *     "LDS size attribute set" cache per kernel and device, and the scratch pool above -- each
+ *     behind its own lock.  No tuning state: every knob is a PER-CALL attribute (md_conv_tune).
  */
 #ifndef MINDDET_HIP_H_
 #define MINDDET_HIP_H_
@@ -55,6 +57,9 @@ extern "C" {
 
 /* library / build info: returns a static string "minddet_hip <ver> gfx950". */
 const char *md_version(void);
+/* frees the scratch pool (stream-ordered: behind the work already queued on each stream).  Optional: call before unloading
+ * the library or to give the memory back; ops called afterwards grow a new pool.  Returns MD_OK / MD_ERR_HIP. */
+int md_scratch_release(void);
 
 /* ------------------------------------------------------------------------------------------
  * Rotated (BEV) IoU + NMS -- same symbol names and parameter lists as the reference's AOT GPU

@@ -1,6 +1,6 @@
 // aot.h -- host-side helpers shared by every entry point of libminddet_hip.so.
 // Argument checking for the MindSpore AOT-operator ABI (see include/minddet_hip.h) and
-// stream-ordered scratch.  No global mutable state except the write-once LDS-attribute cache below.
+// stream-ordered scratch.  Mutable globals: the LDS-attribute cache and the per-stream scratch pool below, nothing else.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -12,6 +12,20 @@
     do {                                       \
         hipError_t e__ = (expr);               \
         if (e__ != hipSuccess) return MD_ERR_HIP; \
+    } while (0)
+
+// Device side: ordering point between LDS writes by SOME lanes of a wave and reads of the same bytes by OTHER lanes of that wave (the
+// wave-private transpose slabs of conv_pingpong_kernel<PERS> and bottleneck64_kernel).  To the language these are different threads with no
+// synchronisation between them, so hipcc may move -- or, around a divergent `if`, duplicate into the non-writing lanes and run first -- the
+// reads across the writes (seen r03: stale rows in exactly those lanes).  A wavefront-scope release / acquire pair orders the memory
+// operations, and wave_barrier is a convergent operation: it can be neither duplicated into nor moved across a divergent region.  All
+// three lower to no instruction (one wave's LDS operations execute in issue order).  r03 used an empty asm with a memory clobber here,
+// which holds only as long as hipcc treats that asm as convergent (r03 ADVICE).
+#define MD_WAVE_LDS_ORDER()                                         \
+    do {                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      \
+        __builtin_amdgcn_wave_barrier();                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      \
     } while (0)
 
 namespace md {
@@ -36,11 +50,68 @@ static inline int64_t numel(int *ndims, int64_t **shapes, int i) {
     return n;
 }
 
-// Scratch: a caller-provided workspace (params[ws_index], size from shapes) or a
-// stream-ordered allocation released by the destructor (hipFreeAsync on the same stream).
+// pool buffers grow in 1 MiB steps, doubling: few regrowths even when the first calls are small
+static inline size_t align_up_pow2_chunk(size_t b) {
+    size_t w = (size_t)1 << 20;
+    while (w < b) w <<= 1;
+    return w;
+}
+
+// Scratch: a caller-provided workspace (params[ws_index], size from shapes) or, when the caller passes none, a buffer of the library's
+// per-(device, stream) pool.  r03: the fallback used to be hipMallocAsync + hipFreeAsync per call, which blocks the host behind queued
+// work (measured ~7 ms per call) -- a MindSpore-side caller binding the ops as INTEGRATION 1 shows would have paid it on
+// every NMS / top-k call.  The pool keeps ONE buffer per stream, grown on demand (hipMallocAsync / hipFreeAsync on that stream, so a
+// queued kernel never loses its memory) and reused by every later call on the stream: steady state makes no driver call at all.  Reuse
+// is safe because an op's kernels and the next op's kernels on one stream execute in order.  md_scratch_release() frees the pool.
+struct ScratchPoolEntry { int dev; hipStream_t stream; void *ptr; size_t bytes; };
+struct ScratchPool {
+    ScratchPoolEntry e[64];
+    int n = 0;
+    int lock = 0;
+};
+inline ScratchPool g_scratch_pool;
+static inline void *pool_acquire(size_t bytes, hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    ScratchPool &P = g_scratch_pool;
+    while (__atomic_exchange_n(&P.lock, 1, __ATOMIC_ACQUIRE)) { }
+    void *out = nullptr;
+    int slot = -1;
+    for (int i = 0; i < P.n; ++i)
+        if (P.e[i].dev == dev && P.e[i].stream == s) { slot = i; break; }
+    if (slot < 0 && P.n < 64) {
+        slot = P.n++;
+        P.e[slot] = {dev, s, nullptr, 0};
+    }
+    if (slot >= 0) {
+        ScratchPoolEntry &en = P.e[slot];
+        if (en.bytes < bytes) {
+            const size_t want = align_up_pow2_chunk(bytes);
+            void *np = nullptr;
+            if (hipMallocAsync(&np, want, s) == hipSuccess) {
+                if (en.ptr) (void)hipFreeAsync(en.ptr, s);   // behind every kernel already queued on s that uses it
+                en.ptr = np;
+                en.bytes = want;
+            }
+        }
+        if (en.bytes >= bytes) out = en.ptr;
+    }
+    __atomic_store_n(&P.lock, 0, __ATOMIC_RELEASE);
+    return out;
+}
+static inline int pool_release() {
+    ScratchPool &P = g_scratch_pool;
+    while (__atomic_exchange_n(&P.lock, 1, __ATOMIC_ACQUIRE)) { }
+    int rc = MD_OK;
+    for (int i = 0; i < P.n; ++i)
+        if (P.e[i].ptr && hipFreeAsync(P.e[i].ptr, P.e[i].stream) != hipSuccess) rc = MD_ERR_HIP;
+    P.n = 0;
+    __atomic_store_n(&P.lock, 0, __ATOMIC_RELEASE);
+    return rc;
+}
 struct Scratch {
     void *ptr = nullptr;
-    bool owned = false;
+    bool owned = false;     // true: more than 64 (device, stream) pairs are live -- a one-call stream-ordered allocation
     hipStream_t stream = nullptr;
     int acquire(size_t bytes, int nparam, void **params, int *ndims, int64_t **shapes, int ws_index,
                 hipStream_t s) {
@@ -53,6 +124,8 @@ struct Scratch {
             owned = false;
             return MD_OK;
         }
+        ptr = pool_acquire(bytes, s);
+        if (ptr) return MD_OK;
         if (hipMallocAsync(&ptr, bytes, s) != hipSuccess) return MD_ERR_HIP;
         owned = true;
         return MD_OK;
@@ -66,9 +139,12 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of once per launch: it is a driver call on the
 // launch path of every layer otherwise (r02 ADVICE; the YOLOv5s step is launch-bound) and would also run inside graph capture.
-// Write-once cache keyed by the kernel's host address (lock-free insert; a full table or a device id >= 8 just sets the attribute again).
-struct LdsAttrSlot { const void *k; int set[8]; };
-static LdsAttrSlot g_lds_attr[128];
+// Cache keyed by the kernel's host address (lock-free insert; a full table or a device id >= 8 just sets the attribute again).  The
+// set-and-store of one slot is serialised by the slot's lock, so the cached value is always the value the driver holds (r03 ADVICE: two
+// host threads raising one kernel's size concurrently could otherwise leave the cache above the driver's value).  This cache is the
+// library's only mutable global besides the per-stream scratch pool below; `inline` gives the whole library ONE instance.
+struct LdsAttrSlot { const void *k; int set[8]; int lock; };
+inline LdsAttrSlot g_lds_attr[128];
 static inline int ensure_dyn_lds(const void *k, int lds) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return MD_ERR_HIP;
@@ -82,9 +158,14 @@ static inline int ensure_dyn_lds(const void *k, int lds) {
         }
         if (cur != k) continue;
         if (__atomic_load_n(&sl.set[dev], __ATOMIC_ACQUIRE) >= lds) return MD_OK;
-        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MD_ERR_HIP;
-        __atomic_store_n(&sl.set[dev], lds, __ATOMIC_RELEASE);
-        return MD_OK;
+        while (__atomic_exchange_n(&sl.lock, 1, __ATOMIC_ACQUIRE)) { }
+        int rc = MD_OK;
+        if (sl.set[dev] < lds) {
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) rc = MD_ERR_HIP;
+            else __atomic_store_n(&sl.set[dev], lds, __ATOMIC_RELEASE);
+        }
+        __atomic_store_n(&sl.lock, 0, __ATOMIC_RELEASE);
+        return rc;
     }
     return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess ? MD_OK : MD_ERR_HIP;
 }

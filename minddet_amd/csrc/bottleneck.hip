@@ -510,7 +510,7 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
                 // The slab is read back by OTHER lanes of the wave, in another vector type: without a compiler-level ordering point hipcc
                 // duplicated the read-out into the lanes that skip the write block and ran it FIRST (stale rows in exactly those lanes' pieces;
                 // found by the bit-compare test).  LDS operations of one wave execute in issue order: no hardware wait is needed.
-                asm volatile("" ::: "memory");
+                MD_WAVE_LDS_ORDER();
     #pragma unroll
                 for (int it = 0; it < 2; ++it) {
                     bn_u32x4 v = *reinterpret_cast<const bn_u32x4 *>(slab + (8 * it + (lane >> 3)) * BN_ES + (lane & 7) * 16);
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, (int)y_off[h * 2 + it], q * 128, 2);
                 }
-                asm volatile("" ::: "memory");   // ... and the next half's writes stay behind this half's reads
+                MD_WAVE_LDS_ORDER();   // ... and the next half's writes stay behind this half's reads
             }
             BN_STAMP(8 + q2);
         }

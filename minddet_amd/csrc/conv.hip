@@ -813,6 +813,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv1x1_stream_kernel(ConvArgs a, 
                 *cell = pk;
             }
         __amdgpu_buffer_rsrc_t ry = y_desc(t);
+        MD_WAVE_LDS_ORDER();   // the cells above were written by other lanes of this wave than the ones that read them out below
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const u32x4 v = *reinterpret_cast<const u32x4 *>(E + i * 1024 + lane * 16);
@@ -1556,7 +1557,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
             // compiler-level ordering points on both sides of the read-out: the slab is written by some lanes and read back by others in
             // another vector type, and hipcc may otherwise move (or duplicate into the non-writing lanes) the reads across the writes --
             // seen in bottleneck64_kernel's slab epilogue (r03).  LDS operations of one wave execute in issue order: no hardware wait.
-            asm volatile("" ::: "memory");
+            MD_WAVE_LDS_ORDER();
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(slab + (e_px + 8 * it) * 144 + e_ch * 16);
@@ -1569,7 +1570,7 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
                 } else
                 __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, v_io + (px0 + 8 * it) * row_b, c0 * 2, 2);
             }
-            asm volatile("" ::: "memory");
+            MD_WAVE_LDS_ORDER();
         };
         if constexpr (MF == 0) {
 #pragma unroll

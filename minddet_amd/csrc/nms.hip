@@ -542,6 +542,7 @@ static inline size_t scan_lds(int cb) { return (size_t)(cb + 1) * sizeof(unsigne
 using namespace md;
 
 extern "C" const char *md_version(void) { return "minddet_hip 0.1 gfx950"; }
+extern "C" int md_scratch_release(void) { return md::pool_release(); }
 
 static int check_boxes7(int nparam, int want, void **params, int *ndims, int64_t **shapes, const char **dtypes,
                         int64_t &n) {

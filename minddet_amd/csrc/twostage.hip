@@ -388,7 +388,7 @@ struct PasteArgs {
 template <bool BITS>
 __global__ __launch_bounds__(256) void paste_masks_kernel(PasteArgs a) {
     constexpr int PX = BITS ? 32 : 4;
-    // 32-bit index arithmetic (the host checks R * H * Ww < 2^32): 64-bit divisions were the larger part of this write-bound kernel's time
+    // 32-bit index arithmetic (the host checks R * H * Ww + one grid stride < 2^32): 64-bit divisions were the larger part of this write-bound kernel's time
     const unsigned total = (unsigned)a.R * (unsigned)a.H * (unsigned)a.Ww;
     for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const unsigned t = e / (unsigned)a.Ww;
@@ -455,7 +455,8 @@ extern "C" int md_paste_masks(MD_AOT_ARGS) {
     if (shapes[2][0] != R || shapes[2][1] != H || shapes[2][2] != (at->bits ? Ww : W)) return MD_ERR_ARG;
     if (R == 0) return MD_OK;
     if (!params[0] || !params[1] || !params[2]) return MD_ERR_ARG;
-    if (R > 0x7fffffffLL / 6 || (long long)R * H * Ww >= 0xffffffffLL) return MD_ERR_SIZE;
+    // the kernel's grid-stride index is 32-bit: e += grid * 256 must not wrap below `total` (r03 ADVICE: it would restart the loop and never end)
+    if (R > 0x7fffffffLL / 6 || (long long)R * H * Ww > 0xffffffffLL - 256LL * 64 * 256) return MD_ERR_SIZE;
     md::PasteArgs a = {(const float *)params[0], (const float *)params[1], params[2], (int)R, (int)S, (int)H, (int)W, (int)Ww, at->threshold};
     const size_t total = (size_t)R * H * Ww, nb = (total + 255) / 256;
     const unsigned grid = (unsigned)(nb < 256u * 64 ? nb : 256u * 64);   // grid-stride: 64 blocks per CU

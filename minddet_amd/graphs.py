@@ -62,7 +62,9 @@ class SplitForward:
             return p[0] if prepare is None else prepare(*p)
 
         cur = torch.cuda.current_stream(dev)
-        key = (step, prepare is not None) + tuple(ins[0].shape[1:])
+        # the model's pack generation is part of the key: .to() after a weight reload drops the lazily built packs (fused blocks, merged
+        # convs), and the pass that rebuilds them must again be a single-stream one (r03 ADVICE: part 1 would read them unsynchronised)
+        key = (getattr(self.model, "_pack_gen", 0), step, prepare is not None) + tuple(ins[0].shape[1:])
         if key not in self._primed:
             self.model.forward(part(0), **kw)
             self._primed.add(key)
@@ -86,6 +88,12 @@ def _split_forward_of(model, test_cfg):
     """test_cfg.streams (default 1) -> model.streams and model.forward_split (== model.forward for one stream)"""
     model.streams = int((test_cfg or {}).get("streams", 1))
     model.forward_split = SplitForward(model, model.streams)
+    model._pack_gen = 0
+
+
+def _packs_rebuilt(model):
+    """called by every detector's .to(): the packed weights (and with them every lazily derived pack) are new objects from here on"""
+    model._pack_gen = getattr(model, "_pack_gen", 0) + 1
 
 
 class ParamInit:
@@ -487,6 +495,7 @@ class FasterRCNN:
     def to(self, device):
         for m in (self.backbone, self.neck, self.rpn_head, self.roi_head):
             m.to(device)
+        _packs_rebuilt(self)
         return self
 
     def conv_modules(self):
@@ -737,6 +746,7 @@ class CenterNet:
     def to(self, device):
         for m in self.conv_modules():
             m.to(device)
+        _packs_rebuilt(self)
         return self
 
     def features(self, images):
@@ -925,6 +935,7 @@ class YOLOv5:
             m.to(device)
         for blk in (self.b2, self.b4, self.b6, self.b8, self.h13, self.h17, self.h20, self.h23):
             blk._cv12 = None     # merged packs are derived copies: rebuilt from the (possibly re-loaded) weights on next use
+        _packs_rebuilt(self)
         # the 3-channel stride-2 stem conv on the 4-channel stem layout (md_stem_conv) when the batch arrives in it
         self.stem = nn_ops.pack_stem_conv(self.b0.weight, bn=self.b0.bn, bias=self.b0.bias, act=self.b0.act)
         if self.stem is not None:
@@ -1076,6 +1087,7 @@ class YOLOv8:
         self.prefix_status = det_ops.PrefixStatus()   # sticky flags of the top-nms_pre cut (see StandardRoIHead)
         self._seg = {}
         self._stem2 = {}
+        _packs_rebuilt(self)
 
     def conv_modules(self):
         out = [self.b0, self.b1, self.b3, self.b5, self.b7, self.h16, self.h19]
@@ -1091,6 +1103,7 @@ class YOLOv8:
         for blk in (self.b2, self.b4, self.b6, self.b8, self.h12, self.h15, self.h18, self.h21):
             blk._cv1 = None      # merged packs are derived copies: rebuilt from the (possibly re-loaded) weights on next use
         self._stem2 = {}
+        _packs_rebuilt(self)
         # the 3-channel stride-2 stem conv on the 4-channel stem layout (md_stem_conv) when the batch arrives in it
         self.stem = nn_ops.pack_stem_conv(self.b0.weight, bn=self.b0.bn, bias=self.b0.bias, act=self.b0.act)
         if self.stem is not None:

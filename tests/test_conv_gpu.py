@@ -771,3 +771,57 @@ def test_pingpong_halo_persistent_and_head_forms_are_bit_identical():
         c_ = nn_ops.conv2d_head(x, pc, pc2)      # the dispatcher's own choice (HALO where its tiles fit): same bits either way
         torch.cuda.synchronize()
         assert torch.equal(a_, b_) and torch.equal(a_, c_), (n, h, w)
+
+
+def test_repeated_bit_compare_of_the_hand_scheduled_kernels():
+    """ONE test that cannot pass on a lucky run (VERDICT r03 item 7 / DESIGN 6d): md_bottleneck in its three residual modes, the persistent
+    and HALO ping-pong forms, the fused head on the HALO form and the stream kernel, 3 shapes x 3 repetitions each against the kernels they
+    replace, every output buffer pre-filled with a sentinel.  r03's intermittent wrong result of the block kernel showed in a loop of this shape
+    every time it was run (and in a single pass only sometimes)."""
+    from minddet_amd import nn_ops
+
+    g = torch.Generator().manual_seed(77)
+    bad = []
+
+    def rep3(tag, fn, ref):
+        out = torch.empty_like(ref)
+        for rep in range(3):
+            out.fill_(7.0)
+            fn(out)
+            torch.cuda.synchronize()
+            if not torch.equal(out, ref):
+                bad.append((tag, rep, int((out != ref).sum())))
+
+    # md_bottleneck: fused downsample conv (MODE 2), identity residual (MODE 0), separate residual tensor (MODE 1)
+    for cin, ds, ext in ((64, True, False), (256, False, False), (256, False, True)):
+        (pc1, pc2, pc3), pd, g2 = _bottleneck_modules(cin, 1000 + cin + int(ext), ds)
+        blk = nn_ops.pack_bottleneck(pc1, pc2, pc3, pd)
+        for shape in ((1, 16, 32), (2, 24, 48), (4, 64, 64)):
+            x = torch.randn(shape + (cin,), generator=g2).to(torch.bfloat16).to(DEV)
+            res = nn_ops.conv2d(x, pd) if ds else (torch.randn(shape + (256,), generator=g2).to(torch.bfloat16).to(DEV) if ext else x)
+            ref = nn_ops.conv2d(nn_ops.conv2d(nn_ops.conv2d(x, pc1), pc2), pc3, residual=res)
+            rep3(("bottleneck", cin, ds, ext, shape), lambda o: nn_ops.bottleneck(x, blk, residual=res if ext else None, out=o), ref)
+    # ping-pong forms: persistent (32), HALO 32x32x16 / 16x16x32 (36 / 37), persistent HALO (38) against the one-tile linear form (15)
+    w = torch.randn((256, 256, 3, 3), generator=g) * (2.0 / 2304) ** 0.5
+    pc = nn_ops.pack_conv(w, bias=torch.randn((256,), generator=g) * 0.1, stride=1, pad=1, relu=True, korder=1).to(DEV)
+    pc2 = nn_ops.pack_conv(torch.randn((15, 256, 1, 1), generator=g) * 0.05, bias=torch.randn((15,), generator=g) * 0.1).to(DEV)
+    for shape in ((2, 40, 56), (3, 50, 84), (1, 100, 168)):
+        x = torch.randn(shape + (256,), generator=g).to(torch.bfloat16).to(DEV)
+        ref = nn_ops.conv2d(x, pc, variant=15)
+        for v in (32, 36, 37, 38):
+            rep3(("pingpong", v, shape), lambda o, v=v: nn_ops.conv2d(x, pc, variant=v, out=o), ref)
+        href = nn_ops.conv2d_head(x, pc, pc2, variant=35)
+        for rep in range(3):
+            got = nn_ops.conv2d_head(x, pc, pc2, variant=34)
+            torch.cuda.synchronize()
+            if not torch.equal(got, href):
+                bad.append(("head halo", shape, rep))
+    # stream kernel (30) with a residual against the tile kernel (20)
+    w1 = torch.randn((1024, 256, 1, 1), generator=g) * (2.0 / 256) ** 0.5
+    ps = nn_ops.pack_conv(w1, bias=torch.randn((1024,), generator=g) * 0.1, relu=True).to(DEV)
+    for shape in ((2, 25, 42), (3, 50, 84), (1, 37, 53)):
+        x = torch.randn(shape + (256,), generator=g).to(torch.bfloat16).to(DEV)
+        r = torch.randn(shape + (1024,), generator=g).to(torch.bfloat16).to(DEV)
+        ref = nn_ops.conv2d(x, ps, residual=r, variant=20)
+        rep3(("stream", shape), lambda o: nn_ops.conv2d(x, ps, residual=r, variant=30, out=o), ref)
+    assert not bad, bad

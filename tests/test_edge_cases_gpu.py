@@ -139,3 +139,38 @@ def test_caller_workspace_is_used():
     assert int(num[0]) == n_o and (keep.cpu().numpy() == k_o).all()
     with pytest.raises(_lib.MindDetHipError, match="rc=4"):  # workspace too small
         _lib.call("boxes_iou_nms_gpu", [bt, torch.tensor([0.3], device=DEV), keep, num, ws[:1000]])
+
+
+def test_scratch_pool_without_a_workspace_param():
+    """a caller that passes NO workspace (a MindSpore binding written as INTEGRATION.md 1 shows) gets the library's
+    per-(device, stream) pool -- same results as with a caller workspace, on two streams at once, repeatedly (the buffer is reused, so call
+    i + 1 must not disturb call i's queued kernels: stream order), with growth (a larger N after a smaller one) and after md_scratch_release."""
+    from minddet_amd import _lib
+    import oracle
+
+    rng = np.random.default_rng(5)
+
+    def boxes(n):
+        b = np.zeros((n, 7), np.float32)
+        b[:, :2] = rng.uniform(-12, 12, (n, 2)); b[:, 3:6] = rng.uniform(1, 4, (n, 3)); b[:, 6] = rng.uniform(-3, 3, n)
+        return b
+
+    sets = [boxes(n) for n in (300, 1500, 700, 4000, 64)]        # grows twice, shrinks in between (no re-allocation then)
+    want = [oracle.nms_rot_aot(b, 0.3) for b in sets]
+    thr = torch.tensor([0.3], device=DEV)
+    s1, s2 = torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)
+    for round_ in range(2):
+        outs = []
+        for i, b in enumerate(sets):
+            st = (s1, s2)[i & 1]
+            with torch.cuda.stream(st):
+                bt = torch.from_numpy(b).to(DEV, non_blocking=False)
+                keep = torch.full((b.shape[0],), -1, dtype=torch.int32, device=DEV)
+                num = torch.full((1,), -1, dtype=torch.int32, device=DEV)
+                _lib.call("boxes_iou_nms_gpu", [bt, thr, keep, num])       # four params: no workspace
+                outs.append((bt, keep, num))
+        torch.cuda.synchronize()
+        for (bt, keep, num), (k_o, n_o) in zip(outs, want):
+            assert int(num[0]) == n_o and (keep.cpu().numpy() == k_o).all()
+        assert _lib.lib().md_scratch_release() == 0                           # the second round starts from an empty pool
+        torch.cuda.synchronize()

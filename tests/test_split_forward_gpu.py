@@ -49,6 +49,33 @@ def test_split_forward_is_bit_identical_tiny(cfgp, hw):
     assert len({k[2] for k in m.prefix_status._t}) >= 3
 
 
+@pytest.mark.parametrize("cfgp,hw", [("configs/faster_rcnn/faster_rcnn_tiny.py", (128, 192)), ("configs/yolov8/yolov8_tiny.py", (128, 160))])
+def test_split_forward_after_weight_reload(cfgp, hw):
+    """r03 ADVICE: .to() after a weight change drops the lazily built packs (fused blocks, merged convs); the pass that rebuilds them must be a
+    single-stream one again -- the priming key carries the model's pack generation"""
+    from minddet.models import Config, build_detector
+    from minddet_amd.graphs import SplitForward
+
+    cfg = Config.fromfile(cfgp)
+    m = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(DEV)
+    x = _images(8, hw[0], hw[1], 5)
+    sp = SplitForward(m, 2)
+    before = sp(x)
+    torch.cuda.synchronize()
+    gen0, n_primed = m._pack_gen, len(sp._primed)
+    for mod in m.conv_modules():          # new weights in every conv
+        mod.weight = mod.weight * 0.5 + 0.01
+    m.to(DEV)
+    assert m._pack_gen == gen0 + 1
+    out = sp(x)                            # must prime again (new key), then fork
+    torch.cuda.synchronize()
+    assert len(sp._primed) == n_primed + 1
+    ref = m.forward(x)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(out, ref))
+    assert not all(torch.equal(a, b) for a, b in zip(out, before))   # the new weights are the ones that ran
+
+
 def test_split_forward_mask_rcnn_r101_bench_shard():
     """configs/mask_rcnn/mask_rcnn_r101_fpn.py enables two streams: at a 8-image batch (two 4-image halves) the outputs, pasted masks included,
     equal the single-stream ones bit for bit"""
