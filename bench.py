@@ -438,8 +438,12 @@ def main(argv=None):
 
     n_streams = args.streams if args.streams is not None else int(getattr(model, "streams", 1))
     if n_streams > 1 and (B % n_streams or not hasattr(model, "forward_split")):
-        sys.stderr.write(f"bench.py: --streams {n_streams} needs a batch divisible by it and a detector with forward_split\n")
-        return 2
+        if args.streams is not None:   # asked for explicitly: an error
+            sys.stderr.write(f"bench.py: --streams {n_streams} needs a batch divisible by it and a detector with forward_split\n")
+            return 2
+        n_streams = 1                  # the config's default cannot split this batch (SplitForward itself would fall back): one stream, reported as such
+    if args.graph:
+        n_streams = 1                  # the captured step is a single-stream model.forward: say so in config.streams
     splitter = None
     if n_streams > 1:
         from minddet_amd.graphs import SplitForward
@@ -504,16 +508,23 @@ def main(argv=None):
     dt = run_timed(step, finish, args.steps, args.warmup, use_dist, torch.cuda.synchronize,
                    lambda: dist.barrier(device_ids=[local_rank]), all_reduce_max, before_timed, on_warmup)
     instrument_off()
+    one_stream = None
     if instrument and splitter is not None and survey:
         # two streams: the dominant kernel's launches are bracketed in a serialized pass of the same steps on ONE stream, outside `dt`
         serial["on"] = True
+        torch.cuda.synchronize()
+        t_s0 = time.perf_counter()
         instrument_on()
         for _ in range(max(args.steps, 1)):
             step()
         finish()
         instrument_off()
-        serial["on"] = False
         torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t_s0
+        serial["on"] = False
+        one_stream = {"ms_per_step": round(dt_s / max(args.steps, 1) * 1e3, 3), "value": round(B * max(args.steps, 1) / dt_s, 2), "steps": max(args.steps, 1),
+                      "what": "the serialized pass the roofline block is measured in: the same steps with the whole batch on ONE stream "
+                              "(events around the dominant kernel's launches), after the timed region"}
     survey = survey or None
     host_enqueue_ms = None if HOST_ENQUEUE["s"] is None else HOST_ENQUEUE["s"] / max(args.steps, 1) * 1e3
     # ... and of ONE step enqueued into an empty queue (device idle before, no synchronisation until the host is done): the pure cost of
@@ -756,7 +767,7 @@ def main(argv=None):
             "config": {"workload": wl, "batch_per_gpu": B, "streams": n_streams,
                        "global_batch": world * B, "parallelism": f"dp{world} (image sharding + all_gather of detections)",
                        "gmac_per_image": None if gmac is None else round(gmac, 2), "weights": "random init, seed 7"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "from_uint8": from_u8, "two_streams": two_streams, "mask_paste": mask_paste,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "from_uint8": from_u8, "two_streams": two_streams, "one_stream": one_stream, "mask_paste": mask_paste,
             # images (over every step of this run) whose class-wise NMS saw a FULL top-nms_pre prefix and fewer than max_det
             # survivors: only those can differ from the NMS over every candidate (DESIGN.md "pre-NMS prefix"); read after timing
             "nms_prefix": None if not hasattr(model, "prefix_status") else {

@@ -12,6 +12,8 @@ model = dict(
                   nms_pre=2048),
 )
 train_cfg = None
-test_cfg = dict(max_per_img=100)
+# streams=2 (r04): the batch runs as two halves on two HIP streams (graphs.SplitForward, bit-identical): +1.0...2.6 % images/s on four boxes in
+# r03 (`two_streams` of the bench line); bench.py measures the roofline block in a serialized one-stream pass after the timed region
+test_cfg = dict(max_per_img=100, streams=2)
 data = dict(img_scale=(1333, 800), pad_divisor=32, input_hw=(800, 1344),
             mean=[0.408, 0.447, 0.470], std=[0.289, 0.274, 0.278])

@@ -188,18 +188,21 @@ def test_end_to_end_agreement_in_map_units():
     """The whole device path against the whole CPU oracle (independent runs, nothing shared at stage boundaries): the oracle's
     detections are the ground truth of a COCO bbox evaluation of the device detections (tests/agreement_ap.py).  Random-init
     weights make every score margin tiny, so one bf16 rounding can swap ranks or NMS survivors and a single 4-image sample swings
-    between 0.87 and 1.0; the MEAN over four seeds of 8 images each is stable.  Measured r02: 0.970 against the oracle that rounds to
+    between 0.87 and 1.0; the MEAN over six seeds of 8 images each is stable.  Measured r02: 0.970 against the oracle that rounds to
     bf16 exactly where the device stores bf16 (per seed 0.93-1.0), 0.911 against the pure fp32 oracle (0.81-0.95)."""
     from tests import agreement_ap
 
-    rs = [agreement_ap.agreement(B=8, seed=seed) for seed in range(4)]
+    rs = [agreement_ap.agreement(B=8, seed=seed) for seed in range(6)]
+    per_seed = [(round(r["bf16-matched oracle"]["AP"], 3), round(r["fp32 oracle"]["AP"], 3)) for r in rs]
+    print("AP per seed (bf16-matched oracle, fp32 oracle):", per_seed)
     assert all(r["bf16-matched oracle"]["n_oracle"] > 40 for r in rs)
     ap_q = sum(r["bf16-matched oracle"]["AP"] for r in rs) / len(rs)
     ar_q = sum(r["bf16-matched oracle"]["AR100"] for r in rs) / len(rs)
     ap_f = sum(r["fp32 oracle"]["AP"] for r in rs) / len(rs)
-    assert ap_q >= 0.93 and ar_q >= 0.94, rs
-    assert min(r["bf16-matched oracle"]["AP"] for r in rs) >= 0.85, rs
-    assert ap_f >= 0.85, rs
+    assert ap_q >= 0.93 and ar_q >= 0.94, per_seed
+    assert min(r["bf16-matched oracle"]["AP"] for r in rs) >= 0.85, per_seed
+    # the independent fp32 oracle: measured 0.911 over these six seeds (r02 / r03); the floor is that value minus the seed-to-seed noise of the mean
+    assert ap_f >= 0.89, per_seed
 
 
 def test_deep_bottleneck_stack_matches_oracle():

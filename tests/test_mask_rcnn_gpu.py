@@ -120,3 +120,61 @@ def test_mask_rcnn_r101_fpn_shard_batch_8():
             if len(ys):
                 assert ys.min() >= np.floor(d[b, i, 1]) - 1 and ys.max() <= np.ceil(d[b, i, 3]) + 1
                 assert xs.min() >= np.floor(d[b, i, 0]) - 1 and xs.max() <= np.ceil(d[b, i, 2]) + 1
+
+
+def _damped_r101(cfg_path, gamma=0.2):
+    """Mask R-CNN R101-FPN whose residual branches end in a BatchNorm with gamma = 0.2: with gamma = 1 the variance doubles in each of the 33
+    random-init blocks and every mask logit saturates (sigmoid gives exact 0 / 1), so a full-size test could compare only the masks' support.
+    Damped, the pyramid stays O(1) and the 28 x 28 mask VALUES are compared with the oracle."""
+    from minddet.models import Config, build_detector
+
+    cfg = Config.fromfile(cfg_path)
+    m = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg)
+    for st in m.backbone.stages:
+        for b in st:
+            g_, beta, mean, var, eps = b.conv3.bn
+            b.conv3.bn = (g_ * gamma, beta, mean, var, eps)
+    return m.to(DEV), cfg
+
+
+def test_mask_rcnn_r101_fpn_bench_batch_32_values_and_two_streams():
+    """every quoted Mask R-CNN number is batch 32 -- so batch 32 is what runs here: one stream and the config's two
+    streams (graphs.SplitForward) bit-identical incl. the pasted masks; proposals / second stage of sampled images bit-exact from the device
+    tensors; and, on a non-saturating init, the mask-head VALUES of sampled detections against the torch-CPU oracle fed the device pyramid
+    (tolerance as the tiny-config test: 6 bf16 conv layers + sigmoid, |dmask| <= 3e-2) and their pasted bit masks bit for bit."""
+    from minddet_amd import det_ops, nn_ops
+    from minddet_amd.data import synthetic_images
+    from oracle import np_ops
+    from tests import stage_checks
+
+    m, cfg = _damped_r101("configs/mask_rcnn/mask_rcnn_r101_fpn.py")
+    assert m.streams == 2
+    B, H, W = 32, 800, 1344
+    x = nn_ops.to_stem_layout(synthetic_images(B, H, W, seed=4242, device=DEV))
+    dets, count, masks, pasted, aux = m.forward(x, return_aux=True, paste=True)
+    torch.cuda.synchronize()
+    assert dets.shape == (B, 100, 6) and masks.shape == (B, 100, 28, 28) and pasted.shape == (B, 100, H, W // 32)
+    for rep in range(2):                                   # the two-stream path the bench line runs (16 + 16 images)
+        d2, c2, m2, p2 = m.forward_split(x, paste=True)
+        torch.cuda.synchronize()
+        assert torch.equal(d2, dets) and torch.equal(c2, count) and torch.equal(m2, masks) and torch.equal(p2, pasted), rep
+    d, c = stage_checks.structure(dets, count, 100, (H, W))
+    assert c.sum() > 0
+    stage_checks.rpn_images(m, aux, (0, 17, 31))
+    stage_checks.roi_images(m, aux, dets, count, (H, W), (0, 17, 31))
+    mk = masks.cpu().numpy()
+    inner = []
+    for b in (0, 17, 31):
+        n = min(int(c[b]), 6)
+        if n == 0:
+            continue
+        feats = [f[b:b + 1].float().cpu().permute(0, 3, 1, 2).contiguous() for f in aux["feats"]]
+        dd = d[b:b + 1, :n].copy()
+        ref = nets.mask_head_forward(m.mask_head, feats, dd, quant=True)[0]
+        assert np.abs(mk[b, :n] - ref).max() <= 3e-2, (b, np.abs(mk[b, :n] - ref).max())
+        inner.append(((mk[b, :n] > 1e-3) & (mk[b, :n] < 1 - 1e-3)).mean())
+        got = det_ops.unpack_mask_bits(pasted[b, :n], W).cpu().numpy()
+        np.testing.assert_array_equal(got, np_ops.paste_masks(mk[b, :n], d[b, :n], (H, W), m.mask_thr))
+    assert inner and min(inner) > 0.5, inner              # the values compared are real probabilities, not saturated 0 / 1
+    for b in range(B):
+        assert (mk[b, c[b]:] == 0).all() and not bool((pasted[b, c[b]:] != 0).any())
