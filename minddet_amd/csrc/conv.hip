@@ -1860,244 +1860,8 @@ static int launch_conv_pingpong_halo(ConvArgs &a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// conv_w128_kernel (r04 experiment): the 256(cout) x 256(pixel) tile on FOUR waves, ONE per SIMD, each owning a
-// 128 x 128 register tile (64 accumulators of v_mfma_f32_16x16x32_bf16 = 256 registers; the kernel runs at 512 registers per lane).
-//
-// Why: the ping-pong kernel reads 0.75 KB of LDS per MFMA-equivalent (per K tile and wave 24 KiB of fragments for 32 32x32x16 MFMAs) and
-// its two waves per SIMD compete for the SIMD's vector issue (on the 16x16x32 shape, which the chip clocks 7-13 % higher, the partner's
-// loads find half the issue slots: r03 stamps, +10 % cycles).  Here a wave reads 0.5 KB per MFMA-equivalent, has its SIMD to itself, and
-// the workgroup passes ONE barrier per 32-deep K step instead of four per 64-deep K tile.
-//
-// K loop: steps of 32 (= one MFMA k-step).  LDS = four stages of [256 A rows | 256 B rows] x 64 B = 128 KiB, filled by LDS-DMA three steps
-// ahead (counted vmcnt: 8 pieces per wave and step, vmcnt(16) = the two youngest steps stay in flight); the fragments of step u + 1 are read
-// into a second register set under the MFMAs of step u.  Per step and wave: 64 MFMAs (1 024 cycles at the SIMD's rate), 16 ds_read_b128,
-// 8 LDS-DMA pieces.
-//   top of step u:  lgkmcnt(0) (own fragments of step u in registers = own reads of stage u & 3 complete); vmcnt(16) (own pieces of step
-//                   u + 1 landed); s_barrier  -> every wave's pieces of step u + 1 are visible, every wave is done reading stage u & 3
-//   body:           DMA step u + 4 -> stage u & 3;  ds_read stage (u + 1) & 3 -> the other register set;  64 MFMAs on this set
-// 64-B rows: the 16-B chunk index is XOR-ed with 3 * ((row >> 2) & 1) on the DMA's source chunk and on the fragment reads -- each
-// ds_read_b128 lane group {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} then touches 16 distinct 16-B slots of the 256-B bank window.
-// Same K order per output element as the other kernels and one fp32 accumulator chain per element: bit-identical to them.
-// ------------------------------------------------------------------------------------------------------------
-template <int GEN, int KORD>   // GEN 0: bias + ReLU-or-none, 2: bias + SiLU; plain / concat output, optional residual (as the ping-pong kernel's GEN 0 / 2).  KORD = a.korder
-__global__ __launch_bounds__(256, 1) void conv_w128_kernel(ConvArgs a) {
-    constexpr int CT = 256, PT = 256, NT = 256;
-    constexpr int SROW = 64;                       // bytes per LDS row (32 bf16)
-    constexpr int STAGE = (CT + PT) * SROW;        // 32 KiB
-    constexpr int EP_STRIDE = CT * 2 + 16;
-    constexpr unsigned OOR = 0x80000000u;
-    typedef __attribute__((address_space(3))) void lds_void;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int l16 = lane & 15, lq = lane >> 4;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int ct = slot % a.n_ctiles, ptl = slot / a.n_ctiles;
-    if (ptl >= a.pt_per_xcd || xcd * a.pt_per_xcd + ptl >= a.n_ptiles) return;
-    const int cout0 = ct * CT, pix0 = (xcd * a.pt_per_xcd + ptl) * PT;
-    const int n_taps = a.kh * a.kw, nk = a.Kpad / 32;
-    const float bias_early = a.bias[cout0 + tid];
-    float *bias_lds = reinterpret_cast<float *>(smem + PT * EP_STRIDE);
-
-    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
-
-    // ---- staging map: one wave instruction = 16 rows x 64 B; wave w stages pieces w, w + 4, w + 8, w + 12 of each operand's 16
-    const int srow = lane >> 2;                                      // row inside a piece
-    const int schunk = (lane & 3) ^ (3 * ((srow >> 2) & 1));         // the logical 16-B chunk this lane's physical slot holds
-    const int a_off = ((cout0 + wave * 16 + srow) * a.Kpad + schunk * 8) * 2;
-    const int a_pass = 64 * a.Kpad * 2;
-    int p_base[4];
-    unsigned p_taps[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = pix0 + (wave + 4 * i) * 16 + srow;
-        p_base[i] = 0; p_taps[i] = 0u;
-        if (a.pointwise) {
-            if (m < a.M) { p_base[i] = m * a.Xs * 2 + schunk * 16; p_taps[i] = 1u; }
-        } else if (m < a.M) {
-            const int n = m / (a.Ho * a.Wo), r = m - n * (a.Ho * a.Wo);
-            const int ho = r / a.Wo, wo = r - ho * a.Wo;
-            const int hi0 = ho * a.stride - a.pad_top, wi0 = wo * a.stride - a.pad_left;
-            p_base[i] = (((n * a.H + hi0) * a.W + wi0) * a.Xs) * 2 + schunk * 16;
-            unsigned bits = 0u, bit = 1u;
-            for (int dy = 0; dy < a.kh; ++dy)
-                for (int dx = 0; dx < a.kw; ++dx, bit <<= 1)
-                    if ((unsigned)(hi0 + dy) < (unsigned)a.H && (unsigned)(wi0 + dx) < (unsigned)a.W) bits |= bit;
-            p_taps[i] = bits;
-        }
-    }
-    // scalar K walk of the step being STAGED: tap (kh, kw) and channel offset of its 32 channels
-    int s_u = 0, s_tap = 0, s_kh = 0, s_kw = 0, s_c = 0, s_half = 0;
-    // one LDS-DMA piece of the step being staged (s_u): pieces 0-3 = A rows (weights), 4-7 = B rows (pixels); stage_advance() after the eighth.
-    // The step's scalars (tap bit, source offset of the tap / channel block, destination, "past the end" bit) are computed ONCE per step
-    // (stage_prepare) -- recomputed per piece they made a B piece ~16 instructions, twice what four MFMAs of a chunk cover.
-    int q_bit = 1, q_soff = 0, q_koff = 0;
-    unsigned q_dead = 0u;
-    char *q_dst = smem;
-    auto stage_prepare = [&]() __attribute__((always_inline)) {
-        q_dst = smem + (s_u & 3) * STAGE + wave * (16 * SROW);
-        q_dead = (unsigned)((nk - 1 - s_u) >> 31) << 31;   // steps past the end: out of range = zero fill (same instruction count)
-        q_koff = (s_u < nk ? s_u : nk - 1) * 64;
-        q_bit = 1 << (s_tap & 31);
-        q_soff = ((s_kh * a.W + s_kw) * a.Xs + s_c) * 2;
-    };
-    auto stage_piece = [&](int q) __attribute__((always_inline)) {
-        if (q < 4) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void *)(q_dst + q * 64 * SROW), 16, (int)((unsigned)(a_off + q * a_pass) | q_dead), q_koff, 0, 0);
-        } else {
-            const int i = q - 4;
-            const unsigned voff = (p_taps[i] & (unsigned)q_bit) ? ((unsigned)(p_base[i] + q_soff) | q_dead) : OOR;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(q_dst + CT * SROW + i * 64 * SROW), 16, (int)voff, 0, 0, 0);
-        }
-    };
-    auto stage_advance = [&]() __attribute__((always_inline)) {
-        ++s_u;
-        // (KORD is a template parameter: with both walks in one function hipcc merged their updates into stores through a SELECTED pointer,
-        // which put the walk's words into scratch memory and its arithmetic into vector registers)
-        if constexpr (KORD == 0) {    // K = (tap, ci)
-            s_c += 32;
-            if (s_c == a.Cin) {
-                s_c = 0; ++s_tap;
-                if (++s_kw == a.kw) { s_kw = 0; ++s_kh; }
-            }
-        } else {                      // K = (ci / 64, tap, ci % 64)
-            s_half ^= 1;
-            s_c ^= 32;
-            if (s_half == 0) {
-                ++s_tap;
-                if (++s_kw == a.kw) { s_kw = 0; ++s_kh; }
-                if (s_tap == n_taps) { s_tap = 0; s_kh = 0; s_kw = 0; s_c += 64; }
-            }
-        }
-    };
-    auto stage_step = [&]() __attribute__((always_inline)) {
-        stage_prepare();
-#pragma unroll
-        for (int q = 0; q < 8; ++q) stage_piece(q);
-        stage_advance();
-    };
-
-    f32x4 acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // fragment offsets inside a stage: row (frag base + l16), 16-B chunk lq ^ 3 * ((l16 >> 2) & 1)
-    const int f_off = l16 * SROW + ((lq ^ (3 * ((l16 >> 2) & 1))) << 4);
-    const int fa_base = (wr * 128) * SROW + f_off, fb_base = CT * SROW + (wc * 128) * SROW + f_off;
-    bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
-
-    // ---- prologue: steps 0-3
-    stage_step(); stage_step(); stage_step(); stage_step();
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");     // step 0 has landed (also retires the older bias load)
-    bias_lds[tid] = bias_early;                           // past the four stages: read in the epilogue
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        fa0[i] = *reinterpret_cast<const bf16x8 *>(smem + fa_base + i * 16 * SROW);
-        fb0[i] = *reinterpret_cast<const bf16x8 *>(smem + fb_base + i * 16 * SROW);
-    }
-
-    // a step = 16 chunks of 4 MFMAs, each pinned by a scheduling barrier (hipcc otherwise issues the eight DMAs with their address
-    // arithmetic as one block in front of the MFMAs).  Chunks 0-7 carry the 16 fragment reads of the NEXT step (two each: they have
-    // returned long before the step ends, so the lgkmcnt(0) in front of the next barrier waits for nothing), chunks 8-15 one LDS-DMA piece each.
-#define W128_CHUNK(G, CA, CB, NA, NB, SN)                                                                              \
-    {                                                                                                                  \
-        constexpr int i_ = (G) >> 1, j0_ = ((G) & 1) * 4;                                                              \
-        _Pragma("unroll") for (int j = j0_; j < j0_ + 4; ++j)                                                          \
-            acc[i_][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CA[i_], CB[j], acc[i_][j], 0, 0, 0);                  \
-        if constexpr ((G) < 8) {                                                                                       \
-            NA[(G)] = *reinterpret_cast<const bf16x8 *>(SN + fa_base + (G) * 16 * SROW);                               \
-            NB[(G)] = *reinterpret_cast<const bf16x8 *>(SN + fb_base + (G) * 16 * SROW);                               \
-        } else stage_piece((G) - 8);                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-    }
-#define W128_STEP(U, CA, CB, NA, NB)                                                                                   \
-    {                                                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                                              \
-        __builtin_amdgcn_s_barrier();                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
-        const char *Sn = smem + (((U) + 1) & 3) * STAGE;                                                               \
-        stage_prepare();                                                                                               \
-        W128_CHUNK(0, CA, CB, NA, NB, Sn) W128_CHUNK(1, CA, CB, NA, NB, Sn) W128_CHUNK(2, CA, CB, NA, NB, Sn) W128_CHUNK(3, CA, CB, NA, NB, Sn)     \
-        W128_CHUNK(4, CA, CB, NA, NB, Sn) W128_CHUNK(5, CA, CB, NA, NB, Sn) W128_CHUNK(6, CA, CB, NA, NB, Sn) W128_CHUNK(7, CA, CB, NA, NB, Sn)     \
-        W128_CHUNK(8, CA, CB, NA, NB, Sn) W128_CHUNK(9, CA, CB, NA, NB, Sn) W128_CHUNK(10, CA, CB, NA, NB, Sn) W128_CHUNK(11, CA, CB, NA, NB, Sn)   \
-        W128_CHUNK(12, CA, CB, NA, NB, Sn) W128_CHUNK(13, CA, CB, NA, NB, Sn) W128_CHUNK(14, CA, CB, NA, NB, Sn) W128_CHUNK(15, CA, CB, NA, NB, Sn) \
-        stage_advance();                                                                                               \
-    }
-
-    for (int u = 0; u < nk; u += 2) {
-        W128_STEP(u, fa0, fb0, fa1, fb1)
-        W128_STEP(u + 1, fa1, fb1, fa0, fb0)
-    }
-#undef W128_STEP
-#undef W128_CHUNK
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero fills of the steps past the end
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // ---- epilogue: bias (+act) -> bf16x4 -> LDS [pixel][cout] -> (+residual, ReLU) -> 16-B NHWC stores
-    constexpr int CPP = CT / 8, EP_ITERS = PT * CPP / NT;
-    char *E = smem;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c_local = wr * 128 + i * 16 + 4 * lq;
-        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias_lds + c_local);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int p_local = wc * 128 + j * 16 + l16;
-            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
-            if (GEN == 0 && a.relu == 1 && !a.res) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-            else if (GEN == 2) { v0 = silu(v0); v1 = silu(v1); v2 = silu(v2); v3 = silu(v3); }
-            u32x2 pk;
-            pk.x = pk_bf16(v0, v1);
-            pk.y = pk_bf16(v2, v3);
-            *reinterpret_cast<u32x2 *>(E + p_local * EP_STRIDE + c_local * 2) = pk;
-        }
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int it = 0; it < EP_ITERS; ++it) {
-        const int e = tid + it * NT;
-        const int p_local = e / CPP, cc = e % CPP;
-        const int m = pix0 + p_local, c = cout0 + cc * 8;
-        if (m >= a.M) continue;
-        u32x4 v = *reinterpret_cast<const u32x4 *>(E + p_local * EP_STRIDE + cc * 16);
-        if (a.res) {
-            const u32x4 rv = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.res + (a.Rs ? (size_t)m * a.Rs + c : (size_t)m * a.Ctot + a.c_off + c)));
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f32x2 sum = (f32x2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)} +
-                                  (f32x2){__uint_as_float(rv[k] << 16), __uint_as_float(rv[k] & 0xffff0000u)};
-                v[k] = pk_bf16(sum.x, sum.y);
-                if (a.relu == 1) v[k] = pk_relu_bf16(v[k]);
-            }
-        }
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.y + (size_t)m * a.Ctot + a.c_off + c));
-    }
-}
-
-static int launch_conv_w128(ConvArgs &a, hipStream_t s) {
-    ++g_launch_count;
-    g_last_kernel = MD_CONV_KERNEL_OTHER;
-    a.n_ctiles = a.Cout / 256;
-    a.n_ptiles = (a.M + 255) / 256;
-    a.pt_per_xcd = (a.n_ptiles + 7) / 8;
-    const long long blocks = (long long)a.n_ctiles * a.pt_per_xcd * 8;
-    if (blocks > 0x7fffffffLL) return MD_ERR_SIZE;
-    const int lds = 256 * (256 * 2 + 16) + 256 * 4;   // the epilogue image (>= the four 32-KiB stages) + bias
-    auto k = a.korder ? (a.relu == 2 ? conv_w128_kernel<2, 1> : conv_w128_kernel<0, 1>) : (a.relu == 2 ? conv_w128_kernel<2, 0> : conv_w128_kernel<0, 0>);
-    if (ensure_dyn_lds((const void *)k, lds) != MD_OK) return MD_ERR_HIP;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, a);
-    return hipGetLastError() == hipSuccess ? MD_OK : MD_ERR_HIP;
-}
-
+// (r04: conv_w128_kernel -- this tile on four waves with a 128 x 128 register tile each -- was built, bit-identical, and measured: it ties
+// this kernel on dense data and loses 4-35 % on zero operands; profiles/r04_w128_experiment.txt, git history has the source.)
 template <int ABL = 0, int MF = 0>
 static int launch_conv_pingpong(ConvArgs &a, hipStream_t s) {
     ++g_launch_count;
@@ -2211,7 +1975,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
     // DMA -> MFMA loop beat 2 double-buffered ones on every benchmark layer (+8...43 %); variant 2 keeps the double buffer
     // (every "auto, except ..." code counts as auto here: r03's first A/Bs of 34 / 35 / 39 / 40 ran their arm on the double-buffered loop
     // and read 1.5 ms per step too slow)
-    a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 25 || (at->variant >= 30 && at->variant <= 41);
+    a.single_buf = at->variant == 0 || at->variant == 20 || at->variant == 25 || (at->variant >= 30 && at->variant <= 40);
     a.stamp = 0; a.dbg = nullptr;
     if ((at->variant >= 17 && at->variant <= 19) || at->variant == 25 || at->variant == 26) {
         // timing ablations / stamp builds: wrong results by construction, so not part of the product library
@@ -2387,12 +2151,6 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
         return variant == 36 ? launch_conv_pingpong<0>(a, s) : launch_conv_pingpong<0, 1>(a, s);
     }
     if (variant == 15 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0>(a, s);  // 256x256 ping-pong, 8 waves
-    // 41: conv_w128_kernel (four waves, 128 x 128 register tile each; r04 experiment) where it applies, else the ping-pong kernel
-    if (variant == 41 && fast && dma_ok && a.Cout % 256 == 0) {
-        const bool plain_out = (!a.adv || (a.os == 1 && a.oy == 0 && a.ox == 0 && a.Ho == a.Hf && a.Wo == a.Wf)) && !a.res_up && (a.Kpad / 32) % 2 == 0 && a.Kpad >= 128;
-        return plain_out ? launch_conv_w128(a, s) : launch_conv_pingpong<0>(a, s);
-    }
-    if (variant == 22 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0, 1>(a, s);  // same, 16x16x32 MFMA
 #ifdef MD_DIAG
     if (variant == 26 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<4, 1>(a, s);   // stamps, 16x16x32 MFMA
     if (variant >= 17 && variant <= 19 && fast && dma_ok && a.Cout % 256 == 0)                       // timing ablations
