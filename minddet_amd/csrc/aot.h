@@ -28,6 +28,27 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      \
     } while (0)
 
+// Device side: every 128-bit buffer store goes through this macro: the store, then `s_nop 1` in an asm statement that takes the stored value
+// as an in / out operand.
+// Why (r04, the root cause of r03's "result that was wrong only sometimes"): gfx950 needs two wait states between a VMEM store of more than
+// 64 bits and a VALU write of its data registers (the store reads them over several cycles).  hipcc inserts them (`s_nop 1`) -- EXCEPT when
+// the store's soffset operand is an SGPR: LLVM's GCNHazardRecognizer::createsVALUHazard exempts that form ("this hazard only exists if the
+// instruction is not using a register in the soffset field"), and on this chip the exemption is wrong.  `buffer_store_dwordx4 v[14:17], v84,
+// s[8:11], s26 offen` directly followed by `v_lshlrev_b32 v14, 16, v86` stored the NEW v14 in the last four lanes of every 16 -- in some
+// tiles of some runs, depending on how long the store waited to issue (profiles/r04_store_data_hazard.txt: reproduced, bisected to one
+// not-even-executed branch that changed the schedule, confirmed by two independent fixes).  Any soffset that is not an inline constant is
+// exposed: a wave-dependent value, but also a literal above 64, which LLVM materialises in an SGPR.  Whether a build is hit depends only on
+// what the scheduler happens to put behind the store -- r03 "fixed" it by rewriting an unrelated expression.
+// The guard: the value is live INTO the asm, so its registers cannot be redefined before it, and the asm itself is the two wait states;
+// anything the scheduler puts between the store and the asm writes other registers.  No register, 8 bytes of code per store, and it does
+// not depend on hipcc's hazard table.  tools/isa_audit.py additionally scans every wide store of every kernel for a VALU write of its
+// data registers within two wait states.  V must be a non-const lvalue.
+#define MD_BUFFER_STORE_B128(V, RSRC, VOFF, SOFF, AUX)                                   \
+    do {                                                                                 \
+        __builtin_amdgcn_raw_buffer_store_b128((V), (RSRC), (int)(VOFF), (SOFF), (AUX)); \
+        asm volatile("s_nop 1" : "+v"(V));                                               \
+    } while (0)
+
 namespace md {
 
 static inline bool dtype_is(const char **dtypes, int i, const char *want) {

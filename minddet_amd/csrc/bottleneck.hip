@@ -523,7 +523,7 @@ __global__ __launch_bounds__(512, 4) void bottleneck64_kernel(BottleneckArgs a) 
                             v[k] = bn_pk_relu(bn_pk_bf16(sum.x, sum.y));
                         }
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, (int)y_off[h * 2 + it], q * 128, 2);
+                    MD_BUFFER_STORE_B128(v, rs_y, y_off[h * 2 + it], q * 128, 2);   // (store + guard: aot.h)
                 }
                 MD_WAVE_LDS_ORDER();   // ... and the next half's writes stay behind this half's reads
             }

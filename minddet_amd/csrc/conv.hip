@@ -816,9 +816,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv1x1_stream_kernel(ConvArgs a, 
         MD_WAVE_LDS_ORDER();   // the cells above were written by other lanes of this wave than the ones that read them out below
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(E + i * 1024 + lane * 16);
-            if (a.tune & 4) __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)yoff[i], 0, 2);
-            else __builtin_amdgcn_raw_buffer_store_b128(v, ry, (int)yoff[i], 0, 0);
+            u32x4 v = *reinterpret_cast<const u32x4 *>(E + i * 1024 + lane * 16);
+            if (a.tune & 4) MD_BUFFER_STORE_B128(v, ry, yoff[i], 0, 2);
+            else MD_BUFFER_STORE_B128(v, ry, yoff[i], 0, 0);
         }
         // the image is free once its read-out has reached the registers: request the next tile's residual into it
         if constexpr (RES != 0) {
@@ -1560,15 +1560,15 @@ __global__ __launch_bounds__(512, 2) void conv_pingpong_kernel(ConvArgs a) {
             MD_WAVE_LDS_ORDER();
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
-                const u32x4 v = *reinterpret_cast<const u32x4 *>(slab + (e_px + 8 * it) * 144 + e_ch * 16);
+                u32x4 v = *reinterpret_cast<const u32x4 *>(slab + (e_px + 8 * it) * 144 + e_ch * 16);
                 if constexpr (HALO) {   // tile-local pixel -> (row, column) by the tile's shape; outside the image: dropped by the range check
                     const int pl = wc * 64 + px0 + 8 * it + e_px;
                     const int row = pl >> cur_twl, col = pl & ((1 << cur_twl) - 1);
                     const bool ok = cur_y0 + row < a.H && cur_x0 + col < a.W;
                     const unsigned off = ok ? (unsigned)(((row * a.W + col) * a.Ctot + wr * 128 + e_ch * 8) * 2) : OOR;
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, (int)off, c0 * 2, 2);
+                    MD_BUFFER_STORE_B128(v, rs_y, off, c0 * 2, 2);
                 } else
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, v_io + (px0 + 8 * it) * row_b, c0 * 2, 2);
+                MD_BUFFER_STORE_B128(v, rs_y, v_io + (px0 + 8 * it) * row_b, c0 * 2, 2);
             }
             MD_WAVE_LDS_ORDER();
         };
@@ -2151,6 +2151,7 @@ static int conv2d_entry(MD_AOT_ARGS, const HeadArgs *head) {
         return variant == 36 ? launch_conv_pingpong<0>(a, s) : launch_conv_pingpong<0, 1>(a, s);
     }
     if (variant == 15 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0>(a, s);  // 256x256 ping-pong, 8 waves
+    if (variant == 22 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<0, 1>(a, s);  // same, 16x16x32 MFMA
 #ifdef MD_DIAG
     if (variant == 26 && fast && dma_ok && a.Cout % 256 == 0) return launch_conv_pingpong<4, 1>(a, s);   // stamps, 16x16x32 MFMA
     if (variant >= 17 && variant <= 19 && fast && dma_ok && a.Cout % 256 == 0)                       // timing ablations

@@ -6,6 +6,9 @@ The hot kernels rely on properties that are invisible in the HIP source and that
   * wave-uniform machinery (`v_readfirstlane_b32`, writes of M0 = the LDS-DMA destination, `buffer_load ... lds`, `s_barrier`) printed behind
     an EXEC mask is LISTED: `readfirstlane` takes the first ACTIVE lane and a masked LDS-DMA writes only the active lanes' bytes, so each
     such site is only correct if its condition is wave-uniform (today: all are `if (wave-derived value)` with an execz skip);
+  * no VALU write of ANY store-of-more-than-64-bits' data registers within two wait states behind it, and every such store with an SGPR
+    soffset followed by its `s_nop` guard (r04: the root cause of r03's intermittent wrong result -- hipcc exempts SGPR-soffset buffer stores from the store-data
+    hazard and gfx950 does not; profiles/r04_store_data_hazard.txt), in EVERY kernel of the audited files, hot or not;
   * no divergent BRANCHES (`s_cbranch_execz / execnz`) between a kernel's first and last MFMA beyond the ones listed for it: r03's rule "no
     divergent control flow inside the phases of these kernels" (DESIGN 6c), checked instead of remembered.  Predication without a branch
     (`s_and_saveexec` ... `s_or_b64 exec`) is allowed and counted.
@@ -64,6 +67,39 @@ def _meta(txt):
     return meta
 
 
+_WIDE_STORE = re.compile(r"(buffer|global|flat|scratch)_store_dwordx[34] (?:\S+ )?v\[(\d+):(\d+)\]")
+_SOFF = re.compile(r"buffer_store_dwordx[34] v\[\d+:\d+\], \S+ s\[\d+:\d+\], (s\d+|m0)\b")
+
+
+def wide_store_hazards(lines):
+    """-> list of findings for one kernel's instruction list: (a) a > 64-bit buffer store whose soffset is an SGPR (hipcc pads nothing
+    behind it); (b) any > 64-bit store followed within two wait states by a VALU instruction that writes one of its data registers."""
+    out = []
+    for i, l in enumerate(lines):
+        m = _WIDE_STORE.search(l)
+        if not m or not l.startswith(m.group(1)):
+            continue
+        sgpr_soff = bool(_SOFF.match(l))   # the form hipcc pads nothing behind: the guard of MD_BUFFER_STORE_B128 must be there
+        lo, hi = int(m.group(2)), int(m.group(3))
+        ws = 0
+        for l2 in lines[i + 1:i + 4]:
+            if l2.startswith("s_nop"):
+                ws += int(l2.split()[1]) + 1
+            else:
+                w = re.match(r"v_\w+ v(\d+)\b|v_\w+ v\[(\d+):(\d+)\]", l2)   # VALU writers only: an LDS / memory load returns tens of cycles later
+                if w and ws < 2:
+                    d0 = int(w.group(1) if w.group(1) is not None else w.group(2))
+                    d1 = int(w.group(3)) if w.group(3) is not None else d0
+                    if d0 <= hi and d1 >= lo:
+                        out.append(f"data register rewritten {ws} wait state(s) behind the store: {l}  ->  {l2}")
+                ws += 1
+            if ws >= 2:
+                break
+        if sgpr_soff and not any(x.startswith("s_nop") for x in lines[i + 1:i + 12]):
+            out.append("SGPR soffset without the s_nop guard behind it: " + l)
+    return out
+
+
 def audit_file(spath):
     txt = open(spath).read()
     meta = _meta(txt)
@@ -77,6 +113,10 @@ def audit_file(spath):
         code = [l for l in f.split("s_endpgm")[0].split("\n")]
         mf = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
         if not mf:
+            sh = wide_store_hazards(lines)
+            if sh:
+                res[m.group(1)] = dict(store_hazards=sh, mfma=0, saveexec=0, exec_branches=0, inner_exec_branches=0, masked_uniform=[],
+                                       **meta.get(m.group(1), dict(vgpr=-1, spill=-1, sgpr_spill=-1, scratch=-1)))
             continue
         # EXEC-mask depth along the printed order.  hipcc prints a structured region's blocks contiguously; a region entered by a branch
         # from elsewhere starts with its own saveexec, so a readfirstlane / M0 write / LDS-DMA at depth > 0 is inside SOME masked region.
@@ -90,14 +130,15 @@ def audit_file(spath):
                                 l.startswith("s_barrier")):
                 masked_uniform.append(l)
         inner = lines[mf[0]:mf[-1] + 1]
-        res[m.group(1)] = dict(mfma=len(mf), saveexec=sum("saveexec" in l for l in lines),
+        store_hazards = wide_store_hazards(lines)
+        res[m.group(1)] = dict(store_hazards=store_hazards, mfma=len(mf), saveexec=sum("saveexec" in l for l in lines),
                                exec_branches=sum(l.startswith("s_cbranch_exec") for l in lines),
                                inner_exec_branches=sum(l.startswith("s_cbranch_exec") for l in inner),
                                masked_uniform=masked_uniform, **meta.get(m.group(1), dict(vgpr=-1, spill=-1, sgpr_spill=-1, scratch=-1)))
     return res
 
 
-def audit(files=("bottleneck.hip", "conv.hip", "stem.hip", "stemconv.hip")):
+def audit(files=("bottleneck.hip", "conv.hip", "stem.hip", "stemconv.hip", "detops.hip", "twostage.hip", "nms.hip", "pool.hip", "preproc.hip", "dcn.hip", "targets.hip")):
     """-> (rows, violations): rows = [(demangled name, stats)], violations = [str]"""
     rows, bad = [], []
     for f in files:
@@ -111,6 +152,8 @@ def audit(files=("bottleneck.hip", "conv.hip", "stem.hip", "stemconv.hip")):
             # SGPR spills -- v_writelane / v_readlane -- exist in the persistent ping-pong forms, all outside the K loop: reported only.
             # A readfirstlane / M0 write / LDS-DMA printed behind a saveexec is reported only too: hipcc lowers wave-uniform `if (wave-derived)`
             # that way with an execz skip, which is correct -- it is listed so that a reader can check the condition IS wave-uniform.)
+            for h in st["store_hazards"]:
+                bad.append(f"{d}: store-data hazard: {h}")
             if hot and (st["spill"] or st["scratch"]):
                 bad.append(f"{d}: {st['spill']} spilled vector registers, {st['scratch']} B of scratch")
             if hot and st["inner_exec_branches"] > HOT[hot[0]]:
