@@ -17,7 +17,7 @@ The JSON line also carries
   roofline     -- the DOMINANT conv kernel by time (md_conv2d_last_kernel attributes every launch; each is bracketed by
                   HIP events on the launch stream) against the roofline that binds its launches in aggregate
                   (algorithmic flops / 2.5 PFLOP/s dense bf16 or algorithmic bytes / 8 TB/s), its PMC traffic from
-                  profiles/r03_conv_traffic.json (null when that file was measured on other kernel sources), and under "all_conv" the same per kernel and for the whole conv/FC set
+                  profiles/rNN_conv_traffic.json of the newest round (null when that file was measured on other kernel sources), and under "all_conv" the same per kernel and for the whole conv/FC set
                   (incl. frac_of_layerwise_roofline = sum of per-launch max(flops/peak, bytes/peak) / measured time).
   cpu_baseline -- the oracle's plain fp32 torch-CPU restatement of the same graph (oracle/nets.py) timed on this
                   host's cores on a bounded sample (rank 0, N=1 only).
@@ -595,9 +595,13 @@ def main(argv=None):
         t_roof_ms = sum(max(r[2] / (PEAK_BF16_TFLOPS * 1e12), r[6] / PEAK_HBM_BPS) for r in all_recs) * 1e3
         traffic = all_traffic = None
         traffic_note = "no PMC file for this library build"
-        tp = os.path.join(ROOT, "profiles", {"FasterRCNN": "r03_conv_traffic.json", "YOLOv5": "r03_yolov5s_conv_traffic.json",
-                                             "YOLOv8": "r03_yolov8l_conv_traffic.json",
-                                             "MaskRCNN": "r03_maskrcnn_conv_traffic.json"}.get(type(model).__name__, "r03_conv_traffic.json"))
+        # the newest round's PMC file for this config (profiles/rNN_<...>conv_traffic.json)
+        import glob
+
+        suffix = {"FasterRCNN": "conv_traffic.json", "YOLOv5": "yolov5s_conv_traffic.json", "YOLOv8": "yolov8l_conv_traffic.json",
+                  "MaskRCNN": "maskrcnn_conv_traffic.json"}.get(type(model).__name__, "conv_traffic.json")
+        cands = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+        tp = cands[-1] if cands else os.path.join(ROOT, "profiles", "r04_" + suffix)
         PMC_PREFIX = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<256, 2, 2, 2, 2, 2,", 3: "conv_igemm_kernel<256, 1, 4,", 5: "conv3x3_halo_kernel",
                       7: "bottleneck64_kernel", 8: "conv1x1_stream_kernel"}  # all instantiations of the kernel
         if os.path.exists(tp):  # PMC passes are separate rocprofv3 runs (tools/pmc_traffic.py); same config only
