@@ -57,8 +57,8 @@ extern "C" {
 
 /* library / build info: returns a static string "minddet_hip <ver> gfx950". */
 const char *md_version(void);
-/* frees the scratch pool (stream-ordered: behind the work already queued on each stream).  Optional: call before unloading
- * the library or to give the memory back; ops called afterwards grow a new pool.  Returns MD_OK / MD_ERR_HIP. */
+/* frees the scratch pool (hipFree: waits for the device).  Optional: call before unloading the library or to give the memory
+ * back; ops called afterwards grow a new pool.  Returns MD_OK / MD_ERR_HIP.  (Under stream capture pass the workspace param.) */
 int md_scratch_release(void);
 
 /* ------------------------------------------------------------------------------------------

@@ -84,6 +84,8 @@ static inline size_t align_up_pow2_chunk(size_t b) {
 // every NMS / top-k call.  The pool keeps ONE buffer per stream, grown on demand (hipMallocAsync / hipFreeAsync on that stream, so a
 // queued kernel never loses its memory) and reused by every later call on the stream: steady state makes no driver call at all.  Reuse
 // is safe because an op's kernels and the next op's kernels on one stream execute in order.  md_scratch_release() frees the pool.
+// Not for use under stream capture: a pool buffer that GROWS inside a captured region would be allocated by the graph -- a captured
+// caller passes the workspace param (as the Python host always does).
 struct ScratchPoolEntry { int dev; hipStream_t stream; void *ptr; size_t bytes; };
 struct ScratchPool {
     ScratchPoolEntry e[64];
@@ -124,8 +126,10 @@ static inline int pool_release() {
     ScratchPool &P = g_scratch_pool;
     while (__atomic_exchange_n(&P.lock, 1, __ATOMIC_ACQUIRE)) { }
     int rc = MD_OK;
+    // hipFree, not hipFreeAsync: a stream the pool remembers may have been destroyed by its owner since (its handle would be invalid);
+    // hipFree waits for the device, which is what a caller releasing memory before unloading the library wants anyway
     for (int i = 0; i < P.n; ++i)
-        if (P.e[i].ptr && hipFreeAsync(P.e[i].ptr, P.e[i].stream) != hipSuccess) rc = MD_ERR_HIP;
+        if (P.e[i].ptr && hipFree(P.e[i].ptr) != hipSuccess) rc = MD_ERR_HIP;
     P.n = 0;
     __atomic_store_n(&P.lock, 0, __ATOMIC_RELEASE);
     return rc;
