@@ -1,5 +1,7 @@
 """conv_w128_kernel (variant 41: four waves, one per SIMD, a 128 x 128 register tile each) against the ping-pong kernel (15 = 32x32x16, 22 = 16x16x32 MFMA)
 on the detector's MFMA-bound layer shapes: bit-compare, then interleaved timing rounds in ONE process on N(0,1) data (guide rule 24 / 25).
+The kernel (variant 41) exists in commit "conv_w128_kernel (experiment)" of round 4 only -- measured, not adopted, removed
+(profiles/r04_w128_experiment.txt); on later trees variant 41 falls through to the dispatcher's own choice.
 python tools/w128_ab.py [rounds] [reps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
