@@ -177,8 +177,11 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemArgs a) {
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const char *src = tile + ((2 * ppy + dy) * ST_CW + 2 * ppx + dx) * ST_TROW + chunk * 32;
-                    const u32x4 v0 = *reinterpret_cast<const u32x4 *>(src), v1 = *reinterpret_cast<const u32x4 *>(src + 16);
+                    // the thread's two 16-B pieces are channels [8 c, 8 c + 8) and [32 + 8 c, ..): the four threads of a pooled pixel then read four
+                    // CONSECUTIVE 16-B slots per instruction (r04; with [16 c, 16 c + 16) they read every second slot and the pixels of a
+                    // ds_read_b128 lane group, 288 B apart, collided 3-way: profiles/r03_lds_bank_conflict_survey.txt)
+                    const char *src = tile + ((2 * ppy + dy) * ST_CW + 2 * ppx + dx) * ST_TROW + chunk * 16;
+                    const u32x4 v0 = *reinterpret_cast<const u32x4 *>(src), v1 = *reinterpret_cast<const u32x4 *>(src + 64);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         o0[e] = pk_max_u16(o0[e], v0[e]);
@@ -186,9 +189,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemArgs a) {
                     }
                 }
             const int py = ty * ST_TPH + ppy, px = tx * ST_TPW + ppx;
-            uint16_t *dst = a.y + (((size_t)n * a.Hq + py) * a.Wq + px) * 64 + chunk * 16;
+            uint16_t *dst = a.y + (((size_t)n * a.Hq + py) * a.Wq + px) * 64 + chunk * 8;
             __builtin_nontemporal_store(o0, reinterpret_cast<u32x4 *>(dst));
-            __builtin_nontemporal_store(o1, reinterpret_cast<u32x4 *>(dst + 8));
+            __builtin_nontemporal_store(o1, reinterpret_cast<u32x4 *>(dst + 32));
         }
     }
 }
