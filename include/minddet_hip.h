@@ -237,6 +237,22 @@ int md_conv2d_head(MD_AOT_ARGS);
  * out: y[N,H,W,256] bf16.   extra: NULL or md_conv_tune (chunk_limit is read). */
 int md_bottleneck(MD_AOT_ARGS);
 
+/* The Bottleneck of a YOLOv5 C3 block (build-authored model of BASELINE configs[1]; the reference names the family only,
+ * README.md:5-14) in ONE launch:  y[.., y_c_off : +C] = x[.., x_c_off : +C] (if shortcut) + silu(conv3x3(silu(conv1x1(x[.., x_c_off : +C])))),
+ * C = 64 or 128 channels in and out, BN folded, stride 1 / pad 1; the C-channel intermediate stays in LDS.  Same arithmetic as the two
+ * md_conv2d launches it replaces (bf16 operands, fp32 accumulation in the same K order, the intermediate and the pre-shortcut value
+ * rounded to bf16): bit-identical to them.  With pass_through the next C channels of x are copied to the next C channels of y (the
+ * cv2(x) half of the C3 concat buffer travels with the result).  x and y must not overlap: MD_ERR_ARG.
+ * in : x[N,H,W,XC] bf16, w1[C,C] bf16, b12[2C] f32 (conv1's biases, then conv2's), w2[C,9C] bf16 (md_conv2d's korder-1 layout:
+ *      K = (ci / 64) * 576 + tap * 64 + ci % 64);  out: y[N,H,W,YC] bf16.   extra: md_c3_pair_attrs (required). */
+typedef struct md_c3_pair_attrs {
+    int32_t x_c_off;       /* first channel of x the pair reads (multiple of 8) */
+    int32_t y_c_off;       /* first channel of y it writes (multiple of 8) */
+    int32_t shortcut;      /* 1: add x (YOLOv5 Bottleneck(shortcut=True)) */
+    int32_t pass_through;  /* 1: also copy x[.., x_c_off + C : + 2C] -> y[.., y_c_off + C : + 2C] */
+} md_c3_pair_attrs;
+int md_c3_pair(MD_AOT_ARGS);
+
 /* Which kernel the dispatcher launched for the calling host thread's most recent md_conv2d (0 before any call, or when
  * the call returned without launching).  Diagnostic only: lets bench.py attribute per-launch HIP-event timings. */
 enum {
@@ -248,7 +264,8 @@ enum {
     MD_CONV_KERNEL_HALO = 5,            /* conv3x3_halo_kernel (3x3 layers with Cout <= 64; variant 11 / 27) */
     MD_CONV_KERNEL_OTHER = 6,           /* A/B variants */
     MD_CONV_KERNEL_BOTTLENECK = 7,      /* bottleneck64_kernel (md_bottleneck) */
-    MD_CONV_KERNEL_STREAM_1X1 = 8       /* conv1x1_stream_kernel: weight-stationary pointwise layers, K <= 512 */
+    MD_CONV_KERNEL_STREAM_1X1 = 8,      /* conv1x1_stream_kernel: weight-stationary pointwise layers, K <= 512 */
+    MD_CONV_KERNEL_C3_PAIR = 9          /* c3pair_kernel (md_c3_pair) */
 };
 int md_conv2d_last_kernel(void);
 /* Running count of the kernels the calling host thread's conv-family calls (md_conv2d, md_conv2d_head, md_conv1x1_dual,

@@ -831,6 +831,9 @@ class RPN:
 
 
 # ----------------------------------------------------------------------------- YOLOv5 (build-authored; parity unpinned)
+C3_PAIR_FUSED = os.environ.get("MD_C3_PAIR", "1") != "0"   # A/B knob (tools/ab_env_bench.sh): 0 = two md_conv2d launches per C3 bottleneck
+
+
 def _yconv(init, cin, cout, k=1, s=1, p=None):
     return ConvModule(init, cin, cout, k, s, k // 2 if p is None else p, bn=True, bn_eps=1e-3, act="silu")
 
@@ -844,18 +847,31 @@ class C3:
         self.m = [(_yconv(init, c_, c_, 1), _yconv(init, c_, c_, 3)) for _ in range(n)]
         self.shortcut, self.c_ = shortcut, c_
         self._cv12 = None
+        self._pairs = None   # md_c3_pair packs of self.m (False: this width is not fused)
 
     def modules(self):
         return [self.cv1, self.cv2, self.cv3] + [m for pair in self.m for m in pair]
 
     def __call__(self, x, x_c_off=None, out=None, c_off=0):
-        """No copies: one launch computes [cv1(x) | cv2(x)] into the concat buffer; every bottleneck then updates channels
-        [0, c_) in place (its 1x1 reads the slice, its 3x3 adds the slice as residual and writes it back: each element is read
-        and written by the same thread)."""
+        """No copies: one launch computes [cv1(x) | cv2(x)] into the concat buffer; every bottleneck then updates channels [0, c_).
+        With 64 or 128 channels a bottleneck is ONE md_c3_pair launch (its 1x1 output stays in LDS; bit-identical): it cannot run in
+        place (a tile's halo pixels are other tiles' outputs), so the blocks alternate between two concat buffers and the last one
+        carries the cv2(x) half along when it ends in the second.  Other widths: two launches per bottleneck, in place (the 1x1 reads the
+        slice, the 3x3 adds the slice as residual and writes it back: each element is read and written by the same thread)."""
         n, h, w, _ = x.shape
         if self._cv12 is None:
             self._cv12 = merged_conv([self.cv1, self.cv2], x.device)
         cat = nn_ops.conv2d(x, self._cv12, x_c_off=x_c_off)
+        if self._pairs is None:
+            pk = [nn_ops.pack_c3_pair(a.packed, b.packed) for a, b in self.m] if C3_PAIR_FUSED else [None]
+            self._pairs = pk if all(p is not None for p in pk) else False
+        if self._pairs:
+            bufs = (cat, torch.empty_like(cat))   # block i reads bufs[i % 2], writes bufs[(i + 1) % 2]; cv2(x) sits in bufs[0]
+            npairs = len(self._pairs)
+            for i, pk in enumerate(self._pairs):
+                # an odd chain ends in bufs[1]: its last block (which reads bufs[0]) carries the cv2(x) half along -- cv3 reads one buffer
+                nn_ops.c3_pair(bufs[i % 2], pk, bufs[(i + 1) % 2], 0, 0, self.shortcut, pass_through=(i + 1 == npairs and npairs % 2 == 1))
+            return self.cv3(bufs[npairs % 2], out=out, c_off=c_off)
         for a, b in self.m:
             t = a(cat, x_c_off=0)
             if self.shortcut:
@@ -934,7 +950,7 @@ class YOLOv5:
         for m in self.conv_modules():
             m.to(device)
         for blk in (self.b2, self.b4, self.b6, self.b8, self.h13, self.h17, self.h20, self.h23):
-            blk._cv12 = None     # merged packs are derived copies: rebuilt from the (possibly re-loaded) weights on next use
+            blk._cv12 = blk._pairs = None     # merged / fused packs are derived copies: rebuilt from the (possibly re-loaded) weights on next use
         _packs_rebuilt(self)
         # the 3-channel stride-2 stem conv on the 4-channel stem layout (md_stem_conv) when the batch arrives in it
         self.stem = nn_ops.pack_stem_conv(self.b0.weight, bn=self.b0.bn, bias=self.b0.bias, act=self.b0.act)

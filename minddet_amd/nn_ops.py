@@ -201,6 +201,41 @@ def bottleneck(x, blk, residual=None, out=None, tune=None):
     return out
 
 
+class _C3PairAttrs(ctypes.Structure):
+    _fields_ = [("x_c_off", ctypes.c_int32), ("y_c_off", ctypes.c_int32), ("shortcut", ctypes.c_int32), ("pass_through", ctypes.c_int32)]
+
+
+class PackedC3Pair:
+    """The (1x1, 3x3) conv pair of a YOLOv5 C3 Bottleneck as md_c3_pair consumes it."""
+
+    def __init__(self, pc1, pc2):
+        self.c = pc1.cin
+        self.w1, self.w2 = pc1.w, pc2.w
+        self.b12 = torch.cat([pc1.bias[:self.c], pc2.bias[:self.c]]).contiguous()
+        self.macs_per_pixel = pc1.cin_real * self.c + 9 * pc2.cin_real * self.c
+
+    def flops_bytes(self, n, h, w, shortcut=True):
+        """algorithmic flops and bytes of the pair as ONE op: x read once, y written once"""
+        px = n * h * w
+        return 2.0 * px * self.macs_per_pixel, 2.0 * (px * 2 * self.c + self.w1.numel() + self.w2.numel())
+
+
+def pack_c3_pair(pc1, pc2):
+    """-> PackedC3Pair if (conv 1x1 + SiLU -> conv 3x3 / s1 / p1 + SiLU) on C = 64 or 128 channels is the shape md_c3_pair fuses, else None"""
+    c = pc1.cin
+    ok = (c in (64, 128) and pc1.kh == 1 and pc1.stride == 1 and pc1.pad == 0 and pc1.relu == 2 and pc1.cout == c and tuple(pc1.w.shape) == (c, c) and
+          pc2.kh == 3 and pc2.kw == 3 and pc2.stride == 1 and pc2.pad == 1 and pc2.relu == 2 and pc2.cin == c and pc2.cout == c and
+          tuple(pc2.w.shape) == (c, 9 * c) and (c == 64 or getattr(pc2, "korder", 0) == 1))
+    return PackedC3Pair(pc1, pc2) if ok else None
+
+
+def c3_pair(x, pk, out, x_c_off=0, y_c_off=0, shortcut=True, pass_through=False):
+    """out[..., y_c_off : +C] = (x[..., x_c_off : +C] if shortcut) + silu(conv3x3(silu(conv1x1(x[..., x_c_off : +C])))) in one md_c3_pair launch;
+    pass_through: out[..., y_c_off + C : + 2C] = x[..., x_c_off + C : + 2C].  `out` must be another buffer than x."""
+    _lib.call("md_c3_pair", [x, pk.w1, pk.b12, pk.w2, out], extra=_C3PairAttrs(int(x_c_off), int(y_c_off), int(bool(shortcut)), int(bool(pass_through))))
+    return out
+
+
 class _DualAttrs(ctypes.Structure):
     _fields_ = [("stride_b", ctypes.c_int32), ("relu", ctypes.c_int32), ("tune", ConvTune)]
 

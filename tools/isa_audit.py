@@ -38,6 +38,9 @@ HOT = {
     "md::conv3x3_halo_kernel": 0,
     "md::stem_pool_kernel": 0,
     "md::stem_conv_kernel": 0,
+    # c3pair: the `halo row inside the image` test of the T1 write-out (between the two MFMA phases: VALU + ds_write only), one per row fragment
+    "md::c3pair64_kernel": 2,
+    "md::c3pair128_kernel": 3,
 }
 
 
@@ -138,7 +141,7 @@ def audit_file(spath):
     return res
 
 
-def audit(files=("bottleneck.hip", "conv.hip", "stem.hip", "stemconv.hip", "detops.hip", "twostage.hip", "nms.hip", "pool.hip", "preproc.hip", "dcn.hip", "targets.hip")):
+def audit(files=("bottleneck.hip", "c3pair.hip", "conv.hip", "stem.hip", "stemconv.hip", "detops.hip", "twostage.hip", "nms.hip", "pool.hip", "preproc.hip", "dcn.hip", "targets.hip")):
     """-> (rows, violations): rows = [(demangled name, stats)], violations = [str]"""
     rows, bad = [], []
     for f in files:
