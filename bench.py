@@ -334,7 +334,7 @@ def main(argv=None):
     launch_count = _lib.lib().md_conv2d_launch_count   # a call on a batch past the 2 GiB chunk limit launches once per image chunk
     launch_count.restype = ctypes.c_longlong
     KNAMES = {1: "conv_pingpong_kernel", 2: "conv_igemm_kernel<128x128>", 3: "conv_igemm_kernel<small cout>",
-              4: "conv_igemm_kernel<generic K>", 5: "conv3x3_halo_kernel", 6: "conv variant", 7: "bottleneck_fused_kernel", 8: "conv1x1_stream_kernel"}
+              4: "conv_igemm_kernel<generic K>", 5: "conv3x3_halo_kernel", 6: "conv variant", 7: "bottleneck_fused_kernel", 8: "conv1x1_stream_kernel", 9: "c3pair_kernel"}
 
     bracket = {"calls": None, "idx": 0}    # calls: None = bracket every launch, else the per-step call indices to bracket
 
@@ -409,6 +409,24 @@ def main(argv=None):
             return y
 
         timed_extra["conv1x1_dual"] = (orig_dual, timed_dual)
+
+    if hasattr(nn_ops, "c3_pair"):
+        orig_c3 = nn_ops.c3_pair
+
+        def timed_c3_pair(x, pk, out, *a_, **kw):
+            if _skip():
+                return orig_c3(x, pk, out, *a_, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            l0 = launch_count()
+            e0.record()
+            y = orig_c3(x, pk, out, *a_, **kw)
+            e1.record()
+            # algorithmic work of the pair as ONE op (x slice read once, y slice written once; the pass-through copy is not counted)
+            fl, byts = pk.flops_bytes(x.shape[0], x.shape[1], x.shape[2])
+            records.append((e0, e1, fl, tuple(x.shape[:3]) + (pk.c,), pk.c, 3, byts, last_kernel(), None, None, launch_count() - l0))
+            return y
+
+        timed_extra["c3_pair"] = (orig_c3, timed_c3_pair)
 
     def instrument_on():
         nn_ops.conv2d, nn_ops.conv2d_head = timed_conv2d, timed_conv2d_head
@@ -693,7 +711,7 @@ def main(argv=None):
         # per-layer table: measured time against the layer's own roofline max(flops / MFMA peak, algorithmic bytes / HBM peak)
         per = {}
         for e0, e1, fl, xs, cout, k, byts, kid, _pc, _pc2, n_l in records:
-            key = f"{xs}->{cout} k{k}" + (" [block]" if kid == 7 else "")
+            key = f"{xs}->{cout} k{k}" + (" [block]" if kid == 7 else (" [1x1 + 3x3 pair]" if kid == 9 else ""))
             d = per.setdefault(key, [0.0, 0.0, 0, 0.0, kid])
             d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += max(n_l, 1); d[3] += byts
         rows = []

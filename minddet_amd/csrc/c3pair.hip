@@ -44,6 +44,7 @@ struct C3PairArgs {
     int N, H, W, XC, YC, x_off, y_off, shortcut, pass;
     int tiles_x, tiles_y, n_tiles, pt_per_xcd;
     unsigned x_bytes, y_bytes;
+    int w1_ld, w2_ld;          // elements per packed weight row (C = 32: 64 / 320, md_conv2d's K padding)
     unsigned long long *dbg;   // MD_DIAG builds only
 };
 
@@ -354,6 +355,167 @@ __device__ __forceinline__ void c3pair_body(const C3PairArgs &a) {
 #endif
 }
 
+// ---- C = 32 (YOLOv5s' first C3 block, 160 x 160 at the benchmark's shard): both weight matrices fit LDS whole (W1 2 KiB, W2 18 KiB), so there
+// is no ring and no barrier inside the phases; 4 waves = the 4 pixel fragments of an 8 x 16 tile (phase A: halo-row fragments w and w + 4),
+// one 32-cout fragment.  Weight rows are padded by 16 B (80 / 592 B: 16 consecutive rows then start in 16 different bank groups), T rows
+// are 64 B with the chunk XOR-swizzled by (row >> 2) & 3.  K order = md_conv2d's for these layers ((tap, ci): korder 0).
+constexpr int C32_TROW = 64, C32_W1ROW = 80, C32_W2ROW = 592;
+constexpr int C32_T = 0, C32_W1 = CP_ROWS * C32_TROW, C32_W2 = C32_W1 + 32 * C32_W1ROW, C32_BIAS = C32_W2 + 32 * C32_W2ROW, C32_LDS = C32_BIAS + 256;
+constexpr int C32_ES = 80;   // epilogue image row stride (over T: 128 x 80 B = 10 KiB)
+__device__ __forceinline__ int c32_swz(int row, int chunk) { return row * C32_TROW + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+__global__ __launch_bounds__(256, 4) void c3pair32_kernel(C3PairArgs a) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr unsigned OOR = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int hp = (int)(((0x73261540u >> ((lr >> 2) * 4)) & 7u) << 2) | (lr & 3);   // (see c3pair_body)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pt = xcd * a.pt_per_xcd + slot;
+    if (pt >= a.n_tiles) return;
+    const int tx = pt % a.tiles_x, ty = (pt / a.tiles_x) % a.tiles_y, n = pt / (a.tiles_x * a.tiles_y);
+    const int y0 = ty * CP_TH, x0 = tx * CP_TW;
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)a.y, 0, a.y_bytes, 0x00020000);
+
+    // x halo tile by LDS-DMA: one wave instruction = 16 rows x 64 B; 12 pieces, wave w stages pieces w, w + 4, w + 8
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int piece = wave + 4 * j;
+        const int r = piece * 16 + (lane >> 2);
+        const int hy = r / CP_HW, hx = r - hy * CP_HW;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const int lchunk = (lane & 3) ^ ((r >> 2) & 3);
+        const bool ok = r < CP_HALO && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const unsigned off = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.XC + a.x_off + lchunk * 8) * 2) : OOR;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void *)(smem + C32_T + piece * 1024), 16, (int)off, 0, 0, 0);
+    }
+    // weights and biases: plain loads -> padded LDS rows (a.w1_ld / a.w2_ld: elements per packed row)
+    {
+        if (tid < 128) {
+            const int row = tid >> 2, ch = tid & 3;
+            const cp_u32x4 v = *reinterpret_cast<const cp_u32x4 *>(a.w1 + row * a.w1_ld + ch * 8);
+            *reinterpret_cast<cp_u32x4 *>(smem + C32_W1 + row * C32_W1ROW + ch * 16) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int e = tid + 256 * it;
+            if (e < 32 * 36) {
+                const int row = e / 36, ch = e - row * 36;
+                const cp_u32x4 v = *reinterpret_cast<const cp_u32x4 *>(a.w2 + row * a.w2_ld + ch * 8);
+                *reinterpret_cast<cp_u32x4 *>(smem + C32_W2 + row * C32_W2ROW + ch * 16) = v;
+            }
+        }
+        if (tid < 64) reinterpret_cast<float *>(smem + C32_BIAS)[tid] = a.b12[tid];
+    }
+    const float *bias12 = reinterpret_cast<const float *>(smem + C32_BIAS);
+    char *T = smem + C32_T;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- phase A: T1 rows of fragments wave, wave + 4
+    cp_f32x16 acc1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const cp_bf16x8 fa = *reinterpret_cast<const cp_bf16x8 *>(smem + C32_W1 + lr * C32_W1ROW + (2 * kk + lh) * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int f = wave + 4 * j;
+            if (f < 6) {
+                const cp_bf16x8 fb = *reinterpret_cast<const cp_bf16x8 *>(T + c32_swz(32 * f + lr, 2 * kk + lh));
+                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc1[j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();   // every wave has read its x fragments
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int f = wave + 4 * j;
+        if (f < 6) {
+            const int r = 32 * f + lr;
+            const int hy = r / CP_HW, hx = r - hy * CP_HW;
+            const bool ok = r < CP_HALO && (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const cp_f32x4 bv = *reinterpret_cast<const cp_f32x4 *>(bias12 + 8 * g + 4 * lh);
+                cp_u32x2 pk;
+                pk.x = cp_pk_bf16(cp_silu(acc1[j][4 * g + 0] + bv.x), cp_silu(acc1[j][4 * g + 1] + bv.y));
+                pk.y = cp_pk_bf16(cp_silu(acc1[j][4 * g + 2] + bv.z), cp_silu(acc1[j][4 * g + 3] + bv.w));
+                if (!ok) pk.x = pk.y = 0u;
+                *reinterpret_cast<cp_u32x2 *>(T + r * C32_TROW + ((g ^ ((r >> 2) & 3)) << 4) + 8 * lh) = pk;
+            }
+        }
+    }
+    // the shortcut values and the pass-through channels of this thread's two output pieces (pixel e / 4, chunk e % 4)
+    auto piece_off = [&](int it, int cstride, int c0) __attribute__((always_inline)) {
+        const int e = tid + 256 * it, p = e >> 2, cc = e & 3;
+        const int yy = y0 + (p >> 4), xx = x0 + (p & 15);
+        return (yy < a.H && xx < a.W) ? (unsigned)((((n * a.H + yy) * a.W + xx) * cstride + c0 + cc * 8) * 2) : OOR;
+    };
+    cp_u32x4 rres[2], pval[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        rres[it] = pval[it] = (cp_u32x4){0u, 0u, 0u, 0u};
+        const unsigned xo = piece_off(it, a.XC, a.x_off);
+        if (a.shortcut) rres[it] = __builtin_bit_cast(cp_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xo, 0, 0));
+        if (a.pass) pval[it] = __builtin_bit_cast(cp_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xo, 64, 0));
+    }
+    __syncthreads();   // T1 complete
+
+    // ---- phase B: pixel fragment = wave
+    cp_f32x16 acc2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+    const int pB = 32 * wave + hp;
+    const int r0 = (pB >> 4) * CP_HW + (pB & 15);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int r = r0 + (t / 3) * CP_HW + (t % 3);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const cp_bf16x8 fa = *reinterpret_cast<const cp_bf16x8 *>(smem + C32_W2 + lr * C32_W2ROW + t * 64 + (2 * kk + lh) * 16);
+            const cp_bf16x8 fb = *reinterpret_cast<const cp_bf16x8 *>(T + c32_swz(r, 2 * kk + lh));
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc2, 0, 0, 0);
+        }
+    }
+    cp_f32x4 bv2[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bv2[g] = *reinterpret_cast<const cp_f32x4 *>(bias12 + 32 + 8 * g + 4 * lh);
+    __syncthreads();   // every wave is done with T1
+    char *E = smem + C32_T;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        cp_u32x2 pk;
+        pk.x = cp_pk_bf16(cp_silu(acc2[4 * g + 0] + bv2[g].x), cp_silu(acc2[4 * g + 1] + bv2[g].y));
+        pk.y = cp_pk_bf16(cp_silu(acc2[4 * g + 2] + bv2[g].z), cp_silu(acc2[4 * g + 3] + bv2[g].w));
+        *reinterpret_cast<cp_u32x2 *>(E + pB * C32_ES + (8 * g + 4 * lh) * 2) = pk;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = tid + 256 * it, p = e >> 2, cc = e & 3;
+        cp_u32x4 v = *reinterpret_cast<const cp_u32x4 *>(E + p * C32_ES + cc * 16);
+        if (a.shortcut) {
+            const cp_u32x4 rv = rres[it];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const cp_f32x2 sum = (cp_f32x2){__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)} +
+                                     (cp_f32x2){__uint_as_float(rv[k] << 16), __uint_as_float(rv[k] & 0xffff0000u)};
+                v[k] = cp_pk_bf16(sum.x, sum.y);
+            }
+        }
+        const unsigned yo = piece_off(it, a.YC, a.y_off);
+        MD_BUFFER_STORE_B128(v, rs_y, yo, 0, 0);
+        if (a.pass) MD_BUFFER_STORE_B128(pval[it], rs_y, yo, 64, 0);
+    }
+}
+
 // (two kernels instead of one template: the register budget differs -- six / four waves per SIMD -- and hipcc's host pass rejects launch
 // bounds that depend on a template parameter)
 __global__ __launch_bounds__(512, 6) void c3pair64_kernel(C3PairArgs a) { c3pair_body<64>(a); }
@@ -369,7 +531,8 @@ extern "C" int md_diag_set_c3_stamp_buffer(void *p) { g_c3_stamp_buf = (unsigned
 #endif
 
 // in : x[N,H,W,XC] bf16, w1[C,C] bf16, b12[2 C] f32 (= b1 | b2), w2[C, 9 C] bf16 (K = (ci / 64) * 576 + tap * 64 + ci % 64: md_conv2d's
-//      korder 1; for C = 64 that is tap * 64 + ci), BN folded, as md_conv2d packs them;  C = 64 or 128
+//      korder 1; for C = 64 that is tap * 64 + ci; C = 32: [32, 64] and [32, 320] with K = tap * 32 + ci, korder 0), BN folded, as md_conv2d packs
+//      them;  C = 32, 64 or 128
 // out: y[N,H,W,YC] bf16 -- another buffer than x (a workgroup's halo pixels are other workgroups' outputs)
 // extra: md_c3_pair_attrs (required)
 extern "C" int md_c3_pair(MD_AOT_ARGS) {
@@ -382,7 +545,8 @@ extern "C" int md_c3_pair(MD_AOT_ARGS) {
     const md_c3_pair_attrs *at = (const md_c3_pair_attrs *)extra;
     const int64_t N = shapes[0][0], H = shapes[0][1], W = shapes[0][2], XC = shapes[0][3], YC = shapes[4][3];
     const int64_t C = shapes[1][0];
-    if ((C != 64 && C != 128) || shapes[1][1] != C || shapes[3][0] != C || shapes[3][1] != 9 * C || numel(ndims, shapes, 2) != 2 * C) return MD_ERR_ARG;
+    const int64_t k1 = (C + 63) / 64 * 64, k2 = (9 * C + 63) / 64 * 64;   // md_conv2d pads the packed K to a multiple of 64
+    if ((C != 32 && C != 64 && C != 128) || shapes[1][1] != k1 || shapes[3][0] != C || shapes[3][1] != k2 || numel(ndims, shapes, 2) != 2 * C) return MD_ERR_ARG;
     if (shapes[4][0] != N || shapes[4][1] != H || shapes[4][2] != W) return MD_ERR_ARG;
     const int64_t span = at->pass_through ? 2 * C : C;
     if (at->x_c_off < 0 || at->y_c_off < 0 || at->x_c_off % 8 || at->y_c_off % 8 || XC % 8 || YC % 8 || at->x_c_off + span > XC || at->y_c_off + span > YC)
@@ -409,14 +573,15 @@ extern "C" int md_c3_pair(MD_AOT_ARGS) {
     a.pt_per_xcd = (a.n_tiles + 7) / 8;
     a.x_bytes = (unsigned)(N * H * W * XC * 2);
     a.y_bytes = (unsigned)(N * H * W * YC * 2);
+    a.w1_ld = (int)k1; a.w2_ld = (int)k2;
     a.dbg = nullptr;
 #ifdef MD_DIAG
     a.dbg = g_c3_stamp_buf;
 #endif
-    void (*k)(C3PairArgs) = C == 64 ? c3pair64_kernel : c3pair128_kernel;
-    const int lds = C == 64 ? CpGeom<64>::LDS : CpGeom<128>::LDS;
+    void (*k)(C3PairArgs) = C == 32 ? c3pair32_kernel : (C == 64 ? c3pair64_kernel : c3pair128_kernel);
+    const int lds = C == 32 ? C32_LDS : (C == 64 ? CpGeom<64>::LDS : CpGeom<128>::LDS);
     if (ensure_dyn_lds((const void *)k, lds) != MD_OK) return MD_ERR_HIP;
-    hipLaunchKernelGGL(k, dim3((unsigned)(a.pt_per_xcd * 8)), dim3(512), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)(a.pt_per_xcd * 8)), dim3(C == 32 ? 256 : 512), lds, (hipStream_t)stream, a);
     md_note_conv_kernel(MD_CONV_KERNEL_C3_PAIR);
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;

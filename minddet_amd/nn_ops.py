@@ -221,11 +221,12 @@ class PackedC3Pair:
 
 
 def pack_c3_pair(pc1, pc2):
-    """-> PackedC3Pair if (conv 1x1 + SiLU -> conv 3x3 / s1 / p1 + SiLU) on C = 64 or 128 channels is the shape md_c3_pair fuses, else None"""
+    """-> PackedC3Pair if (conv 1x1 + SiLU -> conv 3x3 / s1 / p1 + SiLU) on C = 32, 64 or 128 channels is the shape md_c3_pair fuses, else None"""
     c = pc1.cin
-    ok = (c in (64, 128) and pc1.kh == 1 and pc1.stride == 1 and pc1.pad == 0 and pc1.relu == 2 and pc1.cout == c and tuple(pc1.w.shape) == (c, c) and
+    k1, k2 = _round_up(c, 64), _round_up(9 * c, 64)
+    ok = (c in (32, 64, 128) and pc1.kh == 1 and pc1.stride == 1 and pc1.pad == 0 and pc1.relu == 2 and pc1.cout == c and tuple(pc1.w.shape) == (c, k1) and
           pc2.kh == 3 and pc2.kw == 3 and pc2.stride == 1 and pc2.pad == 1 and pc2.relu == 2 and pc2.cin == c and pc2.cout == c and
-          tuple(pc2.w.shape) == (c, 9 * c) and (c == 64 or getattr(pc2, "korder", 0) == 1))
+          tuple(pc2.w.shape) == (c, k2) and getattr(pc2, "korder", 0) == (0 if c == 32 else 1))
     return PackedC3Pair(pc1, pc2) if ok else None
 
 

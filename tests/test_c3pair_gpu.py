@@ -22,6 +22,10 @@ CASES = [
     ("c128_ragged", 3, 21, 50, 128, False, True, 256, 0, 256, 0),
     ("c128_one_tile_exact", 2, 8, 16, 128, True, True, 256, 0, 256, 0),
     ("c128_offsets_no_second_half", 1, 23, 19, 128, True, False, 136, 8, 128, 0),
+    ("c32_ragged", 2, 19, 37, 32, True, False, 64, 0, 64, 0),
+    ("c32_offsets_pass_through", 1, 9, 17, 32, False, True, 96, 32, 72, 8),
+    ("c32_one_tile_exact", 3, 8, 16, 32, True, True, 64, 0, 64, 0),
+    ("c32_yolov5s_p2_shard", 32, 160, 160, 32, True, True, 64, 0, 64, 0),
     ("c64_yolov5s_p3_shard", 32, 80, 80, 64, True, False, 128, 0, 128, 0),
     ("c128_yolov5s_p4_shard", 32, 40, 40, 128, True, True, 256, 0, 256, 0),
 ]
@@ -64,9 +68,14 @@ def test_c3_pair_equals_two_launches_and_fp32(case):
         return   # (the fp32 reference of the full shards takes a minute on the CPU: the small cases cover it)
     xf = x[..., xo:xo + C].float().cpu().permute(0, 3, 1, 2)
 
-    def conv(tt, pc, k, pad):   # the packed weights back in torch's layout (korder 1: (ci / 64, tap, ci % 64))
-        w = pc.w[:C].float().cpu()
-        w = w.view(C, C // 64, k, k, 64).permute(0, 1, 4, 2, 3).reshape(C, C, k, k) if k == 3 else w.view(C, C, 1, 1)
+    def conv(tt, pc, k, pad):   # the packed weights back in torch's layout (K padded to a multiple of 64; korder 1: (ci / 64, tap, ci % 64), 0: (tap, ci))
+        w = pc.w[:C, :k * k * C].float().cpu()
+        if k == 1:
+            w = w.view(C, C, 1, 1)
+        elif getattr(pc, "korder", 0) == 1:
+            w = w.view(C, C // 64, k, k, 64).permute(0, 1, 4, 2, 3).reshape(C, C, k, k)
+        else:
+            w = w.view(C, k, k, C).permute(0, 3, 1, 2)
         return F.conv2d(tt, w, pc.bias[:C].cpu(), padding=pad)
 
     t1 = F.silu(conv(xf, pc1, 1, 0)).to(torch.bfloat16).float()
@@ -97,8 +106,8 @@ def test_c3_pair_argument_checks_and_determinism():
     with pytest.raises(_lib.MindDetHipError):   # another image size
         nn_ops.c3_pair(x, pk, torch.empty((2, 16, 31, 128), dtype=torch.bfloat16, device=DEV), 0, 0, True, False)
     # widths the kernel does not fuse are refused at pack time (the graph then keeps the two launches)
-    pc1b = nn_ops.pack_conv(torch.randn((32, 32, 1, 1), generator=g), relu="silu").to(DEV)
-    pc2b = nn_ops.pack_conv(torch.randn((32, 32, 3, 3), generator=g), stride=1, pad=1, relu="silu").to(DEV)
+    pc1b = nn_ops.pack_conv(torch.randn((256, 256, 1, 1), generator=g), relu="silu").to(DEV)
+    pc2b = nn_ops.pack_conv(torch.randn((256, 256, 3, 3), generator=g), stride=1, pad=1, relu="silu").to(DEV)
     assert nn_ops.pack_c3_pair(pc1b, pc2b) is None
     pc2r = nn_ops.pack_conv(torch.randn((64, 64, 3, 3), generator=g), stride=1, pad=1, relu=True).to(DEV)   # ReLU, not SiLU
     assert nn_ops.pack_c3_pair(pc1, pc2r) is None
@@ -112,7 +121,7 @@ def test_c3_block_fused_equals_unfused():
     (odd chains end in the second concat buffer and carry cv2(x) along), with and without shortcut"""
     from minddet_amd import graphs
 
-    for n, shortcut, c2 in ((1, True, 128), (2, True, 128), (3, True, 256), (1, False, 256), (2, False, 128)):
+    for n, shortcut, c2 in ((1, True, 64), (1, True, 128), (2, True, 128), (3, True, 256), (1, False, 256), (2, False, 128)):
         blk = graphs.C3(graphs.ParamInit(5 + n), c2, c2, n, shortcut)
         for m in blk.modules():
             m.to(DEV)

@@ -25,7 +25,7 @@ def timed(fn, reps=20):
     return sorted(ts)[2]
 
 
-for (N, H, W, C, shortcut, passt) in [(2, 19, 37, 64, True, False), (2, 8, 16, 128, True, True), (3, 21, 50, 128, False, True), (1, 5, 3, 64, True, True),
+for (N, H, W, C, shortcut, passt) in [(2, 19, 37, 32, True, True), (32, 160, 160, 32, True, True), (2, 19, 37, 64, True, False), (2, 8, 16, 128, True, True), (3, 21, 50, 128, False, True), (1, 5, 3, 64, True, True),
                                      (32, 80, 80, 64, True, False), (32, 40, 40, 128, True, True), (32, 40, 40, 128, False, True), (32, 80, 80, 64, False, True)]:
     bn = lambda c: (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5, 1e-3)
     pc1 = nn_ops.pack_conv(torch.randn((C, C, 1, 1), generator=g) * (2.0 / C) ** 0.5, bn=bn(C), relu="silu").to(dev)

@@ -39,6 +39,7 @@ HOT = {
     "md::stem_pool_kernel": 0,
     "md::stem_conv_kernel": 0,
     # c3pair: the `halo row inside the image` test of the T1 write-out (between the two MFMA phases: VALU + ds_write only), one per row fragment
+    "md::c3pair32_kernel": 0,
     "md::c3pair64_kernel": 2,
     "md::c3pair128_kernel": 3,
 }
