@@ -283,6 +283,19 @@ typedef struct md_pool_attrs {
 } md_pool_attrs;
 /* in x[N,H,W,C] bf16 ; out y[N,Ho,Wo,C] bf16.  extra: md_pool_attrs (required). */
 int md_maxpool2d(MD_AOT_ARGS);
+
+/* The pooling chain of an SPPF block (build-authored YOLOv5 / YOLOv8 models; SURVEY 0.2: the reference names the families only) in ONE
+ * launch, in place on the block's concat buffer: with x = buf[.., 0:C],
+ *   buf[.., C:2C] = mp(x), buf[.., 2C:3C] = mp(mp(x)), buf[.., 3C:4C] = mp(mp(mp(x))),  mp = max-pool k x k, stride 1, pad k/2, out-of-image
+ * taps ignored (torch semantics) -- bit-identical to three md_maxpool2d(zero_pad = 0) launches + the copies into the buffer.
+ * in/out: buf[N,H,W,Ctot] bf16 (Ctot >= 4 C, both multiples of 8).  extra: md_sppf_attrs (required).
+ * MD_ERR_SIZE when an image's working set does not fit LDS (md_sppf_pool_groups(H, W, C) == 0): run the three pools instead. */
+typedef struct md_sppf_attrs {
+    int32_t channels;   /* C */
+    int32_t k;          /* window (odd) */
+} md_sppf_attrs;
+int md_sppf_pool(MD_AOT_ARGS);
+int md_sppf_pool_groups(int H, int W, int C);
 /* YOLOv8 Detect decode (anchor-free, distribution focal loss bins; Ultralytics v8 convention; absent from the reference,
  * BASELINE configs[3]: parity unpinned).  in head[B,H,W,Cp] bf16: channels [0, 4*reg_max) = (l,t,r,b) x reg_max bin logits,
  * [4*reg_max, 4*reg_max + nc) = class logits ; out boxes[B,total,4] f32 (xyxy, pixels), scores[B,total] f32 (max class

@@ -831,6 +831,7 @@ class RPN:
 
 
 # ----------------------------------------------------------------------------- YOLOv5 (build-authored; parity unpinned)
+SPPF_FUSED = os.environ.get("MD_SPPF_FUSED", "1") != "0"    # A/B knob: 0 = three md_maxpool2d launches + four concat copies per SPPF block
 C3_PAIR_FUSED = os.environ.get("MD_C3_PAIR", "1") != "0"   # A/B knob (tools/ab_env_bench.sh): 0 = two md_conv2d launches per C3 bottleneck
 
 
@@ -892,6 +893,11 @@ class SPPF:
     def __call__(self, x):
         n, h, w, _ = x.shape
         cat = torch.empty((n, h, w, 4 * self.c_), dtype=torch.bfloat16, device=x.device)
+        if SPPF_FUSED and nn_ops.sppf_pool_fits(h, w, self.c_):
+            # cv1 writes the first slice of the concat buffer; ONE launch fills the other three (md_sppf_pool; bit-identical)
+            self.cv1(x, out=cat, c_off=0)
+            nn_ops.sppf_pool(cat, self.c_, self.k)
+            return self.cv2(cat)
         y = self.cv1(x)
         nn_ops.concat_copy(y, cat, 0)
         for i in range(1, 4):

@@ -352,6 +352,22 @@ def maxpool2d(x, k=3, stride=2, pad=1, zero_pad=True):
     return y
 
 
+class _SppfAttrs(ctypes.Structure):
+    _fields_ = [("channels", ctypes.c_int32), ("k", ctypes.c_int32)]
+
+
+def sppf_pool_fits(h, w, c):
+    """True when md_sppf_pool can hold an h x w image's working set in LDS (else: three maxpool2d launches)"""
+    return _lib.lib().md_sppf_pool_groups(int(h), int(w), int(c)) > 0
+
+
+def sppf_pool(buf, c, k=5):
+    """SPPF's pooling chain in place on its concat buffer [N,H,W,>=4c]: channels [c,2c) = mp(x), [2c,3c) = mp(mp(x)), [3c,4c) = mp(mp(mp(x)))
+    with x = channels [0,c) and mp = max-pool k x k / stride 1 / pad k//2 (torch semantics), one md_sppf_pool launch."""
+    _lib.call("md_sppf_pool", [buf], extra=_SppfAttrs(int(c), int(k)))
+    return buf
+
+
 def upsample_add(lateral, top):
     """FPN top-down: lateral + nearest-upsampled top (to lateral's size)."""
     y = torch.empty_like(lateral)

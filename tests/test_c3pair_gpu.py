@@ -138,3 +138,56 @@ def test_c3_block_fused_equals_unfused():
             graphs.C3_PAIR_FUSED = old
             blk._pairs = None
         assert torch.equal(y, y0), (n, shortcut, c2)
+
+
+@pytest.mark.parametrize("shape", [(32, 20, 20, 256), (2, 20, 20, 512), (3, 13, 17, 64), (1, 1, 1, 8), (2, 5, 40, 24), (1, 40, 40, 128)],
+                         ids=lambda s_: "x".join(str(v) for v in s_))
+def test_sppf_pool_equals_three_maxpools_and_torch(shape):
+    """md_sppf_pool (SPPF's pooling chain, one launch, in place on the concat buffer) against three md_maxpool2d launches + copies (bit
+    compare) and against torch's max_pool2d chain on the same bf16 values (max is exact: equal)."""
+    from minddet_amd import _lib, nn_ops
+
+    N, H, W, C = shape
+    assert nn_ops.sppf_pool_fits(H, W, C)
+    g = torch.Generator().manual_seed(H * 31 + C)
+    x = torch.randn((N, H, W, C), generator=g).to(torch.bfloat16)
+    for k in (5, 3):
+        cat = torch.full((N, H, W, 4 * C + 8), 7.0, dtype=torch.bfloat16)
+        cat[..., :C] = x
+        cat = cat.to(DEV)
+        nn_ops.sppf_pool(cat, C, k)
+        ref = [x.to(DEV)]
+        for _ in range(3):
+            ref.append(nn_ops.maxpool2d(ref[-1], k, 1, k // 2, zero_pad=False))
+        torch.cuda.synchronize()
+        t = x.float().permute(0, 3, 1, 2)
+        for i in range(4):
+            assert torch.equal(cat[..., i * C:(i + 1) * C], ref[i]), (k, i)
+            assert torch.equal(cat[..., i * C:(i + 1) * C].float().cpu(), t.permute(0, 2, 3, 1)), (k, i, "torch")
+            t = F.max_pool2d(t, k, 1, k // 2)
+        assert bool((cat[..., 4 * C:] == 7.0).all())
+    # argument checks: a buffer narrower than 4 C, an even window; a map too large for LDS is refused with a size error (the graph falls back)
+    with pytest.raises(_lib.MindDetHipError):
+        nn_ops.sppf_pool(torch.empty((1, 4, 4, 3 * C), dtype=torch.bfloat16, device=DEV), C, 5)
+    with pytest.raises(_lib.MindDetHipError):
+        nn_ops.sppf_pool(torch.empty((1, 4, 4, 4 * C), dtype=torch.bfloat16, device=DEV), C, 4)
+    assert not nn_ops.sppf_pool_fits(80, 80, 64)
+    with pytest.raises(_lib.MindDetHipError):
+        nn_ops.sppf_pool(torch.empty((1, 80, 80, 256), dtype=torch.bfloat16, device=DEV), 64, 5)
+
+
+def test_sppf_block_fused_equals_unfused():
+    from minddet_amd import graphs
+
+    blk = graphs.SPPF(graphs.ParamInit(3), 128, 128)
+    for m in blk.modules():
+        m.to(DEV)
+    x = torch.randn((2, 20, 24, 128), generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).to(DEV)
+    y = blk(x)
+    old = graphs.SPPF_FUSED
+    graphs.SPPF_FUSED = False
+    try:
+        y0 = blk(x)
+    finally:
+        graphs.SPPF_FUSED = old
+    assert torch.equal(y, y0)
