@@ -214,8 +214,16 @@ __device__ __forceinline__ float funord(unsigned o) {
     return __uint_as_float(u);
 }
 
+#ifdef MD_DIAG
+// tools/topk_stamps.py: cycle stamps of segment 0's workgroup (thread 0)
+__device__ unsigned long long *g_topk_stamps = nullptr;
+#define TK_STAMP(I) do { if (g_topk_stamps && blockIdx.x == 0 && threadIdx.x == 0) g_topk_stamps[I] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TK_STAMP(I) do { } while (0)
+#endif
 constexpr int TOPK_THREADS = 1024;
 constexpr int TOPK_MAXK = 4096;
+constexpr int TOPK_LDS_MAX_N = 30000;   // longest segment whose keys topk_segmented_lds_kernel stages in LDS (and registers)
 
 // Histogram increment with wave-level aggregation.  Detector scores are heavily concentrated (bf16
 // logits: a handful of distinct top bytes), so a plain LDS atomic per lane serialises 64-deep on one
@@ -234,25 +242,122 @@ __device__ __forceinline__ void hist_add_aggregated(unsigned *hist, bool active,
     }
 }
 
+// sorts sel[0, P) ascending (P a power of two, P <= E * TOPK_THREADS, and P == E * TOPK_THREADS when E > 1); all threads of the
+// workgroup call it; sel is complete (barrier) before and after
+template <int E>
+__device__ __forceinline__ void topk_bitonic_regs(unsigned long long *sel, int P) {
+    const int tid = threadIdx.x;
+    const bool on = tid * E < P;
+    unsigned long long v[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) v[j] = on ? sel[tid * E + j] : ~0ull;
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= 64 * E) {
+                __syncthreads();   // (the previous LDS stage's reads are done)
+                if (on) {
+#pragma unroll
+                    for (int j = 0; j < E; ++j) sel[tid * E + j] = v[j];
+                }
+                __syncthreads();
+                if (on) {
+#pragma unroll
+                    for (int j = 0; j < E; ++j) {
+                        const int g = tid * E + j;
+                        const unsigned long long b = sel[g ^ stride];
+                        const bool up = (g & size) == 0, low = (g & stride) == 0;
+                        v[j] = ((v[j] < b) == (low == up)) ? v[j] : b;
+                    }
+                }
+            } else if (stride >= E) {
+                const int lm = stride / E;   // partner lane = lane ^ lm, same register
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    const unsigned long long b = __shfl_xor(v[j], lm, 64);
+                    const int g = tid * E + j;
+                    const bool up = (g & size) == 0, low = (g & stride) == 0;
+                    v[j] = ((v[j] < b) == (low == up)) ? v[j] : b;
+                }
+            } else {   // partners are two of this thread's registers
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    if ((j & stride) == 0 && (j | stride) < E) {
+                        const int g = tid * E + j;
+                        const bool up = (g & size) == 0;
+                        const unsigned long long a = v[j], b = v[j | stride];
+                        const bool swap = (a > b) == up;
+                        v[j] = swap ? b : a;
+                        v[j | stride] = swap ? a : b;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) sel[tid * E + j] = v[j];
+    }
+}
+
 // One workgroup per segment.  Selects the k largest scores strictly greater than min_score
 // (ties resolved towards the LOWER index), returns them sorted descending (stable).
 // seg_off[L+1] (int32, elements).  out_val/out_idx are [L,k]; padded with (-FLT_MAX, 0); out_cnt[L].
+// LK: the segment's ordinal keys are staged in LDS first (`lkeys`, n entries) and every later pass reads them there: the passes are
+// chains of dependent loads, and from L2 each link costs a round trip (r04: YOLOv5s' 25 200 scores per image).
+template <bool LK = false>
 __device__ void topk_block_select(const float *__restrict__ scores, const int *__restrict__ seg_off, int seg, int k,
                                   float min_score, float *__restrict__ out_val, int *__restrict__ out_idx,
-                                  int *__restrict__ out_cnt, unsigned long long *sel /* LDS, TOPK_MAXK entries */) {
+                                  int *__restrict__ out_cnt, unsigned long long *sel /* LDS, TOPK_MAXK entries */,
+                                  unsigned *lkeys = nullptr) {
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_remaining, s_count, s_wave_base[TOPK_THREADS / 64], s_tie_taken, s_tie_total;
     const int tid = threadIdx.x;
     const int beg = seg_off[seg], n = seg_off[seg + 1] - beg;
     const float *sc = scores + beg;
     const unsigned omin = ford(min_score);
+    TK_STAMP(0);
+    // LK: this thread's keys (elements tid, tid + 1024, ...) also stay in REGISTERS: the sweeps below -- count, four radix passes, compaction --
+    // then cost a handful of instructions per element (r04: 25 loop iterations of ~100 instructions per sweep were most of the kernel)
+    constexpr int PER = LK ? (TOPK_LDS_MAX_N + TOPK_THREADS - 1) / TOPK_THREADS : 1;
+    unsigned rk[PER];
+    if constexpr (LK) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = tid + j * TOPK_THREADS;
+            rk[j] = i < n ? ford(sc[i]) : 0u;   // independent loads: all in flight together
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = tid + j * TOPK_THREADS;
+            if (i < n) lkeys[i] = rk[j];        // (the LDS copy serves the ordered tie pass, which stops early)
+        }
+        __syncthreads();
+    }
+    auto key_at = [&](int i) __attribute__((always_inline)) { return LK ? lkeys[i] : ford(sc[i]); };
+    // one sweep over the segment with a uniform trip count (ballots inside the bodies): body(index, key or 0 beyond the end)
+    auto sweep = [&](auto body) __attribute__((always_inline)) {
+        if constexpr (LK) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                if (j * TOPK_THREADS >= n) break;
+                body(j * TOPK_THREADS + tid, rk[j]);
+            }
+        } else {
+            for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {
+                const int i = i0 + tid;
+                body(i, i < n ? ford(sc[i]) : 0u);
+            }
+        }
+    };
 
+    TK_STAMP(1);
     // count selectable elements
     if (tid == 0) s_count = 0;
     __syncthreads();
     {
         unsigned c = 0;
-        for (int i = tid; i < n; i += TOPK_THREADS) c += ford(sc[i]) > omin ? 1u : 0u;
+        sweep([&](int i, unsigned u) { c += (i < n && u > omin) ? 1u : 0u; });
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
         if ((tid & 63) == 0 && c) atomicAdd(&s_count, c);
     }
@@ -263,28 +368,41 @@ __device__ void topk_block_select(const float *__restrict__ scores, const int *_
     while (P < kk) P <<= 1;
     for (int i = tid; i < P; i += TOPK_THREADS) sel[i] = ~0ull;
 
+    TK_STAMP(2);
     unsigned prefix = 0, maskbits = 0, remaining = (unsigned)kk;
     if (kk > 0 && kk < avail) {
         for (int pass = 0; pass < 4; ++pass) {
             const int shift = 24 - 8 * pass;
             for (int i = tid; i < 256; i += TOPK_THREADS) hist[i] = 0;
             __syncthreads();
-            for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {   // uniform trip count: ballots inside
-                const int i = i0 + tid;
-                const unsigned u = i < n ? ford(sc[i]) : 0u;
+            sweep([&](int i, unsigned u) {
                 const bool act = i < n && u > omin && (u & maskbits) == prefix;
                 hist_add_aggregated(hist, act, (u >> shift) & 255u);
+            });
+            __syncthreads();
+            // the digit's bin: the largest b with count(bins >= b) >= remaining.  Threads 0..255 own one bin each and take the suffix sums with
+            // wave shuffles (r04: one thread walking the 256 bins paid an LDS round trip per bin, four times per segment: a third of the kernel)
+            unsigned h_bin = 0, suf = 0;
+            if (tid < 256) {
+                h_bin = hist[tid];
+                suf = h_bin;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned t = __shfl_down(suf, o, 64);
+                    if ((tid & 63) + o < 64) suf += t;
+                }
+                if ((tid & 63) == 0) s_wave_base[tid >> 6] = suf;
             }
             __syncthreads();
-            if (tid == 0) {
-                unsigned c = 0, rem = remaining;
-                int b = 255;
-                for (; b > 0; --b) {
-                    if (c + hist[b] >= rem) break;
-                    c += hist[b];
+            if (tid < 256) {
+                unsigned s_incl = suf;
+                for (int w = (tid >> 6) + 1; w < 4; ++w) s_incl += s_wave_base[w];
+                const unsigned above = s_incl - h_bin, rem = remaining;
+                // (bin 0 also takes the case no bin reaches `remaining`, as the serial walk did)
+                if ((s_incl >= rem && above < rem) || (tid == 0 && s_incl < rem)) {
+                    s_prefix = prefix | ((unsigned)tid << shift);
+                    s_remaining = rem - above;
                 }
-                s_prefix = prefix | ((unsigned)b << shift);
-                s_remaining = rem - c;
             }
             __syncthreads();
             prefix = s_prefix;
@@ -298,21 +416,29 @@ __device__ void topk_block_select(const float *__restrict__ scores, const int *_
         remaining = 0;
     }
     const unsigned thr = prefix;  // exact ordinal of the kk-th largest (or omin)
+    TK_STAMP(3);
 
     // compaction, part 1: strictly-greater elements in any order; count the copies of the k-th value
     if (tid == 0) { s_count = 0; s_tie_taken = 0; s_tie_total = 0; }
     __syncthreads();
     {
         unsigned ties = 0;
-        for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {
-            const int i = i0 + tid;
-            const unsigned u = i < n ? ford(sc[i]) : 0u;
-            if (i < n && u > omin && u > thr) {
-                const unsigned pos = atomicAdd(&s_count, 1u);
-                if (pos < (unsigned)TOPK_MAXK) sel[pos] = ((unsigned long long)(~u) << 32) | (unsigned)i;
+        sweep([&](int i, unsigned u) {
+            // one LDS atomic per wave reserves the wave's slots (r04: one same-address atomic per selected element serialised -- 4096 of them)
+            const bool take = i < n && u > omin && u > thr;
+            const unsigned long long bal = __ballot(take);
+            if (bal != 0ull) {
+                const int ln = tid & 63, leader = __ffsll((long long)bal) - 1;
+                unsigned base_pos = 0;
+                if (ln == leader) base_pos = atomicAdd(&s_count, (unsigned)__popcll(bal));
+                base_pos = __builtin_amdgcn_readlane(base_pos, leader);
+                if (take) {
+                    const unsigned pos = base_pos + (unsigned)__popcll(bal & ((1ull << ln) - 1ull));
+                    if (pos < (unsigned)TOPK_MAXK) sel[pos] = ((unsigned long long)(~u) << 32) | (unsigned)i;
+                }
             }
             ties += (i < n && u > omin && u == thr && remaining > 0) ? 1u : 0u;
-        }
+        });
         for (int o = 32; o > 0; o >>= 1) ties += __shfl_xor(ties, o, 64);
         if ((tid & 63) == 0 && ties) atomicAdd(&s_tie_total, ties);
     }
@@ -321,19 +447,17 @@ __device__ void topk_block_select(const float *__restrict__ scores, const int *_
     // orders by (value, index)): no barriers.  r01: the barrier-per-1024-elements ordered scan used to run for every segment --
     // 48 barriers on the 16 384-element CenterNet maps.  It is needed only when the k-th value has more copies than are missing.
     if (remaining > 0 && s_tie_total == remaining) {
-        for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {
-            const int i = i0 + tid;
-            const unsigned u = i < n ? ford(sc[i]) : 0u;
+        sweep([&](int i, unsigned u) {
             if (i < n && u > omin && u == thr) {
                 const unsigned pos = (unsigned)kk - remaining + atomicAdd(&s_tie_taken, 1u);
                 sel[pos] = ((unsigned long long)(~u) << 32) | (unsigned)i;
             }
-        }
+        });
     } else if (remaining > 0) {
         // ordered (index-ascending) selection of the first `remaining` copies; stops (uniformly) once they are found
         for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {
             const int i = i0 + tid;
-            const unsigned u = i < n ? ford(sc[i]) : 0u;
+            const unsigned u = i < n ? key_at(i) : 0u;
             const bool tie = i < n && u > omin && u == thr;
             const unsigned long long bal = __ballot(tie);
             const int wv = tid >> 6, ln = tid & 63;
@@ -356,19 +480,16 @@ __device__ void topk_block_select(const float *__restrict__ scores, const int *_
     }
     // (greater elements occupy [0, kk-remaining), ties [kk-remaining, kk))
     // bitonic sort ascending on (~key, idx)  == key descending, index ascending
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int t = tid; t < P / 2; t += TOPK_THREADS) {
-                const int lo = 2 * t - (t & (stride - 1));
-                const int hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const unsigned long long a = sel[lo], b = sel[hi];
-                if ((a > b) == up) { sel[lo] = b; sel[hi] = a; }
-            }
-        }
-    }
+    TK_STAMP(4);
+    // bitonic sort, ascending keys.  Thread t keeps entries t E .. t E + E - 1 in registers: a stage whose partners are less than E apart is
+    // register-to-register, less than 64 E apart a wave shuffle, and only the farther ones (10 of the 78 stages at P = 4096) go through
+    // LDS with workgroup barriers (r04: one barrier + LDS round trip per stage was 33 of the kernel's 73 us on YOLOv5s' segments)
     __syncthreads();
+    if (P > 2048) topk_bitonic_regs<4>(sel, P);
+    else if (P > 1024) topk_bitonic_regs<2>(sel, P);
+    else topk_bitonic_regs<1>(sel, P);
+    __syncthreads();
+    TK_STAMP(5);
     for (int i = tid; i < k; i += TOPK_THREADS) {
         float v = -FLT_MAX;
         int id = 0;
@@ -381,6 +502,7 @@ __device__ void topk_block_select(const float *__restrict__ scores, const int *_
         out_idx[(size_t)seg * k + i] = id;
     }
     if (tid == 0) out_cnt[seg] = kk;
+    TK_STAMP(6);
 }
 
 __global__ __launch_bounds__(TOPK_THREADS) void topk_segmented_kernel(const float *__restrict__ scores,
@@ -390,6 +512,18 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_segmented_kernel(const floa
                                                                       int *__restrict__ out_cnt) {
     __shared__ unsigned long long sel[TOPK_MAXK];
     topk_block_select(scores, seg_off, blockIdx.x, k, min_score, out_val, out_idx, out_cnt, sel);
+}
+
+// segments of at most `cap` (<= TOPK_LDS_MAX_N) scores: keys staged in dynamic LDS; a longer segment (a caller's max_segment that was
+// not a bound after all) takes the global-memory passes
+__global__ __launch_bounds__(TOPK_THREADS) void topk_segmented_lds_kernel(const float *__restrict__ scores, const int *__restrict__ seg_off, int k,
+                                                                          float min_score, float *__restrict__ out_val, int *__restrict__ out_idx,
+                                                                          int *__restrict__ out_cnt, int cap) {
+    __shared__ unsigned long long sel[TOPK_MAXK];
+    extern __shared__ __attribute__((aligned(16))) unsigned topk_lkeys[];
+    const int n = seg_off[blockIdx.x + 1] - seg_off[blockIdx.x];
+    if (n <= cap) topk_block_select<true>(scores, seg_off, blockIdx.x, k, min_score, out_val, out_idx, out_cnt, sel, topk_lkeys);
+    else topk_block_select<false>(scores, seg_off, blockIdx.x, k, min_score, out_val, out_idx, out_cnt, sel);
 }
 
 // ---- multi-workgroup path for long segments (RPN level P2: 201 600 scores per image).
@@ -1071,6 +1205,12 @@ __global__ void sigmoid_clip_kernel(const float *__restrict__ x, float *__restri
 
 using namespace md;
 
+#ifdef MD_DIAG
+extern "C" int md_diag_set_topk_stamp_buffer(void *p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(md::g_topk_stamps), &p, sizeof(p)) == hipSuccess ? MD_OK : MD_ERR_HIP;
+}
+#endif
+
 extern "C" int md_anchors_fpn(MD_AOT_ARGS) {
     if (nparam != 1) return MD_ERR_NPARAM;
     if (!params || !extra || !dtype_is(dtypes, 0, "float32")) return MD_ERR_ARG;
@@ -1262,6 +1402,12 @@ extern "C" int md_topk_segmented(MD_AOT_ARGS) {
         hipLaunchKernelGGL(topk_final_kernel, dim3((unsigned)L), dim3(TOPK_THREADS), 0, s, (const float *)params[0],
                            (const int *)params[1], at->k, at->min_score, cand_cnt, cand, (float *)params[2],
                            (int *)params[3], (int *)params[4]);
+    } else if (at->max_segment > 0 && at->max_segment <= TOPK_LDS_MAX_N) {
+        const int cap = at->max_segment;
+        const int lds = (int)align_up((size_t)cap * 4, 16);
+        if (ensure_dyn_lds((const void *)topk_segmented_lds_kernel, lds) != MD_OK) return MD_ERR_HIP;
+        hipLaunchKernelGGL(topk_segmented_lds_kernel, dim3((unsigned)L), dim3(TOPK_THREADS), lds, s, (const float *)params[0],
+                           (const int *)params[1], at->k, at->min_score, (float *)params[2], (int *)params[3], (int *)params[4], cap);
     } else {
         hipLaunchKernelGGL(topk_segmented_kernel, dim3((unsigned)L), dim3(TOPK_THREADS), 0, s, (const float *)params[0],
                            (const int *)params[1], at->k, at->min_score, (float *)params[2], (int *)params[3],
