@@ -206,7 +206,7 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("conv.hip", "bottleneck.hip", "stem.hip", "stemconv.hip", "aot.h"):
+    for f in ("conv.hip", "bottleneck.hip", "c3pair.hip", "stem.hip", "stemconv.hip", "aot.h"):
         with open(os.path.join(ROOT, "minddet_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()

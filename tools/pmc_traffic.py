@@ -21,11 +21,11 @@ def per_kernel(d):
 fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
 steps = int(sys.argv[3])
 batch = int(sys.argv[4])
-conv = [k for k in fetch if "conv_igemm_kernel" in k or "conv3x3_halo_kernel" in k or "conv_pingpong_kernel" in k or "bottleneck64_kernel" in k or "conv1x1_stream_kernel" in k]
+conv = [k for k in fetch if "conv_igemm_kernel" in k or "conv3x3_halo_kernel" in k or "conv_pingpong_kernel" in k or "bottleneck64_kernel" in k or "conv1x1_stream_kernel" in k or "c3pair" in k]
 f_kb = sum(fetch[k][0] for k in conv)
 w_kb = sum(write[k][0] for k in conv)
 n = sum(fetch[k][1] for k in conv)
-out = {"kernel": "conv_pingpong_kernel + conv_igemm_kernel + conv3x3_halo_kernel + bottleneck64_kernel + conv1x1_stream_kernel (all conv/FC launches)", "profiled_steps": steps,
+out = {"kernel": "conv_pingpong_kernel + conv_igemm_kernel + conv3x3_halo_kernel + bottleneck64_kernel + conv1x1_stream_kernel + c3pair kernels (all conv/FC launches)", "profiled_steps": steps,
        "batch_per_gpu": batch, "launches": n,
        "FETCH_SIZE_KB_raw": f_kb, "WRITE_SIZE_KB": w_kb, "fetch_correction": 2.0,
        "hbm_bytes_per_step": (2.0 * f_kb + w_kb) * 1024 / steps,
