@@ -171,12 +171,13 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(uint16_t *__restrict__ b
         a0[i] = v;
     }
     __syncthreads();
+    // (a tap beyond the image edge is replaced by the edge pixel, which is inside every window that reaches the edge: max is idempotent, so
+    // that equals ignoring it -- and the loops have no branch, all their LDS reads are independent and issue back to back)
     for (int i = threadIdx.x; i < items; i += 256) {   // row maxima of radius R, 2R, 3R
         const int px = i / CC, c = px % W;
         u32x4 m = a0[i];
         for (int d = 1; d <= 3 * R; ++d) {
-            if (c - d >= 0) m = sp_max(m, a0[i - d * CC]);
-            if (c + d < W) m = sp_max(m, a0[i + d * CC]);
+            m = sp_max(m, sp_max(a0[i - min(d, c) * CC], a0[i + min(d, W - 1 - c) * CC]));
             if (d == R) a1[i] = m;
             if (d == 2 * R) a2[i] = m;
         }
@@ -188,17 +189,10 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(uint16_t *__restrict__ b
         const int px = i / CC, ch = i - px * CC, r = px / W;
         u32x4 m1 = a1[i], m2 = a2[i], m3 = a3[i];
         for (int d = 1; d <= 3 * R; ++d) {
-            const bool up = r - d >= 0, dn = r + d < H;
-            if (up) m3 = sp_max(m3, a3[i - d * rs]);
-            if (dn) m3 = sp_max(m3, a3[i + d * rs]);
-            if (d <= 2 * R) {
-                if (up) m2 = sp_max(m2, a2[i - d * rs]);
-                if (dn) m2 = sp_max(m2, a2[i + d * rs]);
-            }
-            if (d <= R) {
-                if (up) m1 = sp_max(m1, a1[i - d * rs]);
-                if (dn) m1 = sp_max(m1, a1[i + d * rs]);
-            }
+            const int up = min(d, r) * rs, dn = min(d, H - 1 - r) * rs;
+            m3 = sp_max(m3, sp_max(a3[i - up], a3[i + dn]));
+            if (d <= 2 * R) m2 = sp_max(m2, sp_max(a2[i - up], a2[i + dn]));
+            if (d <= R) m1 = sp_max(m1, sp_max(a1[i - up], a1[i + dn]));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) { m1[q] = sp_unkey(m1[q]); m2[q] = sp_unkey(m2[q]); m3[q] = sp_unkey(m3[q]); }

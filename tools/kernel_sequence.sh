@@ -1,9 +1,9 @@
 #!/bin/bash
 # kernel launch sequence of ONE bench step (rocprofv3 kernel trace, sorted by start time): which launches sit between the convs
 # usage: bash tools/kernel_sequence.sh <config> <batch> <out.txt>
-CFG=$1; B=$2; OUT=$3
+CFG=$1; B=$2; OUT=$3; shift 3   # further arguments go to bench.py (e.g. --streams 1)
 ROOT=$(pwd); D=$ROOT/gpurun_out/kseq; rm -rf $D; mkdir -p $D $(dirname $OUT)
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $D -- python3 $ROOT/bench.py --config $ROOT/$CFG --batch $B --steps 2 --warmup 2 --no-cpu-baseline --no-roofline --no-zero-operands --no-from-uint8 > $D/log.txt 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $D -- python3 $ROOT/bench.py --config $ROOT/$CFG --batch $B --steps 2 --warmup 2 --no-cpu-baseline --no-roofline --no-zero-operands --no-from-uint8 "$@" > $D/log.txt 2>&1)
 f=$(ls $D/*/*kernel_trace.csv | head -1)
 python3 - "$f" "$OUT" <<'PY'
 import csv, sys
