@@ -70,5 +70,46 @@ ref = nn_ops.stem_conv(x4, ps)
 n_bad = sum(0 if torch.equal(nn_ops.stem_conv(x4, ps), ref) else 1 for _ in range(REPS))
 bad += n_bad
 print(f"stem_conv 6x6 b32: {REPS} runs, {n_bad} mismatches", flush=True)
+# r04: md_c3_pair (three widths) against the two launches, md_sppf_pool against three md_maxpool2d, md_topk_segmented (LDS form) against its first result
+for C, H in ((32, 160), (64, 80), (128, 40)):
+    bnp = lambda c: (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5, 1e-3)
+    q1 = nn_ops.pack_conv(torch.randn((C, C, 1, 1), generator=g) * (2.0 / C) ** 0.5, bn=bnp(C), relu="silu").to(dev)
+    q2 = nn_ops.pack_conv(torch.randn((C, C, 3, 3), generator=g) * (2.0 / (9 * C)) ** 0.5, bn=bnp(C), stride=1, pad=1, relu="silu").to(dev)
+    pk = nn_ops.pack_c3_pair(q1, q2)
+    x = torch.randn((32, H, H, 2 * C), generator=g).to(torch.bfloat16).to(dev)
+    ref = nn_ops.conv2d(nn_ops.conv2d(x, q1, x_c_off=0), q2, residual=x, res_c_off=0)
+    y = torch.empty_like(x)
+    n_bad = 0
+    for _ in range(REPS):
+        y.fill_(7.0)
+        nn_ops.c3_pair(x, pk, y, 0, 0, True, True)
+        n_bad += 0 if (torch.equal(y[..., :C], ref) and torch.equal(y[..., C:], x[..., C:])) else 1
+    bad += n_bad
+    print(f"md_c3_pair C {C} @{H}x{H} b32: {REPS} runs, {n_bad} mismatches", flush=True)
+xs_ = torch.randn((32, 20, 20, 256), generator=g).to(torch.bfloat16)
+refs = [xs_.to(dev)]
+for _ in range(3):
+    refs.append(nn_ops.maxpool2d(refs[-1], 5, 1, 2, zero_pad=False))
+ref = torch.cat(refs, 3)
+n_bad = 0
+for _ in range(REPS):
+    cat = torch.full((32, 20, 20, 1024), 7.0, dtype=torch.bfloat16, device=dev)
+    cat[..., :256] = refs[0]
+    nn_ops.sppf_pool(cat, 256, 5)
+    n_bad += 0 if torch.equal(cat, ref) else 1
+bad += n_bad
+print(f"md_sppf_pool 32x20x20x256: {REPS} runs, {n_bad} mismatches", flush=True)
+from minddet_amd import det_ops
+sc = torch.rand((32 * 25200,), generator=g).to(dev)
+seg = torch.arange(0, 33 * 25200, 25200, dtype=torch.int32, device=dev)
+v0, i0, c0 = det_ops.topk_segmented(sc, seg, 4096, min_score=0.25, max_segment=25200)
+vs, order = torch.sort(sc.view(32, 25200), dim=1, descending=True, stable=True)
+assert torch.equal(v0, vs[:, :4096]) and torch.equal(i0.long(), order[:, :4096])
+n_bad = 0
+for _ in range(REPS):
+    v, i, c = det_ops.topk_segmented(sc, seg, 4096, min_score=0.25, max_segment=25200)
+    n_bad += 0 if (torch.equal(v, v0) and torch.equal(i, i0) and torch.equal(c, c0)) else 1
+bad += n_bad
+print(f"md_topk_segmented 32 x 25200, k 4096 (equal to torch.sort(stable) once, then to itself): {REPS} runs, {n_bad} mismatches", flush=True)
 print("TOTAL MISMATCHES", bad)
 sys.exit(1 if bad else 0)
