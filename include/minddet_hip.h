@@ -395,7 +395,12 @@ int md_slice_cast(MD_AOT_ARGS);
  * in src[N,H,W,C] bf16 ; out dst[N,H,W,Ctot] bf16 (only channels [c0, c0+C) are written).  extra: md_slice_attrs
  * (c0 = destination offset, width = C) */
 int md_concat_copy(MD_AOT_ARGS);
-/* nearest 2x upsample into a channel slice: in src[N,H,W,C] bf16 ; out dst[N,2H,2W,Ctot] bf16.  extra: md_slice_attrs */
+/* nearest 2x upsample of a channel slice into a channel slice: in src[N,H,W,Cs] bf16 (channels [src_c0, src_c0 + width) are read) ;
+ * out dst[N,2H,2W,Ctot] bf16 (channels [c0, c0 + width) are written).  extra: md_upsample2x_attrs (required) */
+typedef struct md_upsample2x_attrs {
+    int32_t c0, width;   /* destination offset, channels copied */
+    int32_t src_c0;      /* first source channel */
+} md_upsample2x_attrs;
 int md_upsample2x(MD_AOT_ARGS);
 /* in x[N,H,W,C] bf16 ; out y[N,width,H,W] f32 (NCHW, the layout centernet/src/decode.py consumes) */
 int md_nhwc_to_nchw_f32(MD_AOT_ARGS);

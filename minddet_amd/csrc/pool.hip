@@ -123,8 +123,9 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const uint16_t *_
 }
 
 // dst[n,h,w,c0+c] = src[n,h/up,w/up,c]  (up = 1: channel-slice copy; up = 2: nearest upsample into a slice)
+// (the source may itself be a channel slice [sc0, sc0 + C) of a tensor with Cs channels)
 __global__ void slice_write_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int N, int H, int W, int C,
-                                   int Ctot, int c0, int up) {
+                                   int Ctot, int c0, int up, int Cs, int sc0) {
     const int cv = C / 8;
     const size_t total = (size_t)N * H * W * cv;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -134,7 +135,7 @@ __global__ void slice_write_kernel(const uint16_t *__restrict__ src, uint16_t *_
         const int h = (int)(p % H);
         const int n = (int)(p / H);
         const int Hs = H / up, Ws = W / up;
-        const u32x4 v = *reinterpret_cast<const u32x4 *>(src + (((size_t)n * Hs + h / up) * Ws + w / up) * C + c8 * 8);
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(src + (((size_t)n * Hs + h / up) * Ws + w / up) * Cs + sc0 + c8 * 8);
         *reinterpret_cast<u32x4 *>(dst + (((size_t)n * H + h) * W + w) * Ctot + c0 + c8 * 8) = v;
     }
 }
@@ -301,16 +302,19 @@ static int slice_write_impl(MD_AOT_ARGS, int up) {
     if (nparam != 2) return MD_ERR_NPARAM;
     if (!params || !extra || !ndims || !shapes || ndims[0] != 4 || ndims[1] != 4) return MD_ERR_ARG;
     if (!dtype_is(dtypes, 0, "bfloat16") || !dtype_is(dtypes, 1, "bfloat16")) return MD_ERR_ARG;
-    const md_slice_attrs *at = (const md_slice_attrs *)extra;
-    const int N = (int)shapes[0][0], Hs = (int)shapes[0][1], Ws = (int)shapes[0][2], C = (int)shapes[0][3];
+    // md_concat_copy: md_slice_attrs {c0, width}; md_upsample2x: md_upsample2x_attrs {c0, width, src_c0} (the source may be a channel slice)
+    const md_upsample2x_attrs *at = (const md_upsample2x_attrs *)extra;
+    const int sc0 = up == 2 ? at->src_c0 : 0;
+    const int N = (int)shapes[0][0], Hs = (int)shapes[0][1], Ws = (int)shapes[0][2], Cs = (int)shapes[0][3];
+    const int C = up == 2 ? at->width : Cs;
     const int H = (int)shapes[1][1], W = (int)shapes[1][2], Ctot = (int)shapes[1][3];
-    if (shapes[1][0] != N || H != Hs * up || W != Ws * up || C % 8 || Ctot % 8 || at->c0 % 8 || at->c0 < 0 ||
-        at->width != C || at->c0 + C > Ctot)
+    if (shapes[1][0] != N || H != Hs * up || W != Ws * up || C < 8 || C % 8 || Cs % 8 || Ctot % 8 || at->c0 % 8 || at->c0 < 0 || sc0 % 8 || sc0 < 0 ||
+        at->width != C || at->c0 + C > Ctot || sc0 + C > Cs)
         return MD_ERR_ARG;
     const size_t total = (size_t)N * H * W * (C / 8);
     if (total == 0) return MD_OK;
     hipLaunchKernelGGL(slice_write_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t *)params[0], (uint16_t *)params[1], N, H, W, C, Ctot, at->c0, up);
+                       (const uint16_t *)params[0], (uint16_t *)params[1], N, H, W, C, Ctot, at->c0, up, Cs, sc0);
     MD_HIP_TRY(hipGetLastError());
     return MD_OK;
 }

@@ -890,20 +890,20 @@ class SPPF:
     def modules(self):
         return [self.cv1, self.cv2]
 
-    def __call__(self, x):
+    def __call__(self, x, out=None, c_off=0):
         n, h, w, _ = x.shape
         cat = torch.empty((n, h, w, 4 * self.c_), dtype=torch.bfloat16, device=x.device)
         if SPPF_FUSED and nn_ops.sppf_pool_fits(h, w, self.c_):
             # cv1 writes the first slice of the concat buffer; ONE launch fills the other three (md_sppf_pool; bit-identical)
             self.cv1(x, out=cat, c_off=0)
             nn_ops.sppf_pool(cat, self.c_, self.k)
-            return self.cv2(cat)
+            return self.cv2(cat, out=out, c_off=c_off)
         y = self.cv1(x)
         nn_ops.concat_copy(y, cat, 0)
         for i in range(1, 4):
             y = nn_ops.maxpool2d(y, self.k, 1, self.k // 2, zero_pad=False)
             nn_ops.concat_copy(y, cat, i * self.c_)
-        return self.cv2(cat)
+        return self.cv2(cat, out=out, c_off=c_off)
 
 
 @DETECTORS.register_module
@@ -985,21 +985,23 @@ class YOLOv5:
         cat13 = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=x.device)
         self.b6(x, out=cat13, c_off=c)
         x = self.b9(self.b8(self.b7(cat13, x_c_off=c)))
-        h10 = self.h10(x)
-        nn_ops.upsample2x(h10, cat13, 0)
-        h14 = self.h14(self.h13(cat13))
-        nn_ops.upsample2x(h14, cat17, 0)
+        # h10 / h14 are written straight into the second half of the bottom-up concat buffers that consume them later ([downsampled | top]);
+        # the top-down upsample reads them there as a channel slice (r04: two concat copies less)
+        n, h, w, _ = x.shape
+        c = self.h10.cout
+        cat23 = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=x.device)
+        self.h10(x, out=cat23, c_off=c)
+        nn_ops.upsample2x(cat23, cat13, 0, src_c0=c, width=c)
+        n, h, w, _ = cat13.shape
+        c = self.h14.cout
+        cat20 = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=x.device)
+        self.h14(self.h13(cat13), out=cat20, c_off=c)
+        nn_ops.upsample2x(cat20, cat17, 0, src_c0=c, width=c)
         o3 = self.h17(cat17)
-        n, h, w, c = h14.shape
-        cat = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=x.device)
-        self.h18(o3, out=cat, c_off=0)
-        nn_ops.concat_copy(h14, cat, c)
-        o4 = self.h20(cat)
-        n, h, w, c = h10.shape
-        cat = torch.empty((n, h, w, 2 * c), dtype=torch.bfloat16, device=x.device)
-        self.h21(o4, out=cat, c_off=0)
-        nn_ops.concat_copy(h10, cat, c)
-        o5 = self.h23(cat)
+        self.h18(o3, out=cat20, c_off=0)
+        o4 = self.h20(cat20)
+        self.h21(o4, out=cat23, c_off=0)
+        o5 = self.h23(cat23)
         return [d(o) for d, o in zip(self.detect, (o3, o4, o5))]
 
     def forward(self, images, return_aux=False):
@@ -1152,21 +1154,24 @@ class YOLOv8:
         c_top = self.b9.cv2.cout
         cat12 = torch.empty((n, h, w, c_top + self.b6.cv2.cout), dtype=torch.bfloat16, device=x.device)
         self.b6(x, out=cat12, c_off=c_top)
-        p5 = self.b9(self.b8(self.b7(cat12, x_c_off=c_top)))
-        nn_ops.upsample2x(p5, cat12, 0)
-        h12 = self.h12(cat12)
-        nn_ops.upsample2x(h12, cat15, 0)
+        # p5 / h12 are written straight into the second part of the bottom-up concat buffers that consume them later ([downsampled | top]);
+        # the top-down upsample reads them there as a channel slice (r04: two concat copies less)
+        x = self.b8(self.b7(cat12, x_c_off=c_top))
+        n, h, w, _ = x.shape
+        c19, c5 = self.h19.cout, self.b9.cv2.cout
+        cat21 = torch.empty((n, h, w, c19 + c5), dtype=torch.bfloat16, device=x.device)
+        self.b9(x, out=cat21, c_off=c19)
+        nn_ops.upsample2x(cat21, cat12, 0, src_c0=c19, width=c5)
+        n, h, w, _ = cat12.shape
+        c16, c12 = self.h16.cout, self.h12.cv2.cout
+        cat18 = torch.empty((n, h, w, c16 + c12), dtype=torch.bfloat16, device=x.device)
+        self.h12(cat12, out=cat18, c_off=c16)
+        nn_ops.upsample2x(cat18, cat15, 0, src_c0=c16, width=c12)
         o3 = self.h15(cat15)
-        n, h, w, c = h12.shape
-        cat = torch.empty((n, h, w, o3.shape[3] + c), dtype=torch.bfloat16, device=x.device)
-        self.h16(o3, out=cat, c_off=0)
-        nn_ops.concat_copy(h12, cat, o3.shape[3])
-        o4 = self.h18(cat)
-        n, h, w, c = p5.shape
-        cat = torch.empty((n, h, w, o4.shape[3] + c), dtype=torch.bfloat16, device=x.device)
-        self.h19(o4, out=cat, c_off=0)
-        nn_ops.concat_copy(p5, cat, o4.shape[3])
-        o5 = self.h21(cat)
+        self.h16(o3, out=cat18, c_off=0)
+        o4 = self.h18(cat18)
+        self.h19(o4, out=cat21, c_off=0)
+        o5 = self.h21(cat21)
         heads = []
         for f, bx, cl in zip((o3, o4, o5), self.box, self.cls):
             n, h, w, _ = f.shape

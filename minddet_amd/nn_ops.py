@@ -396,12 +396,18 @@ def concat_copy(src, dst, c0):
     return dst
 
 
-def upsample2x(src, dst=None, c0=0):
-    """Nearest 2x upsample, optionally straight into channels [c0, c0+C) of a wider `dst`."""
-    n, h, w, c = src.shape
+class _Upsample2xAttrs(ctypes.Structure):
+    _fields_ = [("c0", ctypes.c_int32), ("width", ctypes.c_int32), ("src_c0", ctypes.c_int32)]
+
+
+def upsample2x(src, dst=None, c0=0, src_c0=0, width=None):
+    """Nearest 2x upsample of channels [src_c0, src_c0 + width) of `src` (default: all of it), optionally straight into channels
+    [c0, c0 + width) of a wider `dst`."""
+    n, h, w, cs = src.shape
+    c = cs - src_c0 if width is None else width
     if dst is None:
         dst = torch.empty((n, 2 * h, 2 * w, c), dtype=torch.bfloat16, device=src.device)
-    _lib.call("md_upsample2x", [src, dst], extra=_SliceAttrs(int(c0), c))
+    _lib.call("md_upsample2x", [src, dst], extra=_Upsample2xAttrs(int(c0), int(c), int(src_c0)))
     return dst
 
 

@@ -122,6 +122,12 @@ def test_silu_residual_conv_and_slice_writes():
     nn_ops.upsample2x(x.to(DEV), dst, 32)
     up = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
     assert torch.equal(dst[..., 32:].float().cpu(), up) and float(dst[..., :32].abs().sum()) == 0
+    # the source as a channel slice of a wider tensor (r04: the top-down upsample reads a feature where its producer wrote it for the bottom-up concat)
+    dst3 = torch.zeros((1, 40, 48, 40), dtype=torch.bfloat16, device=DEV)
+    nn_ops.upsample2x(x.to(DEV), dst3, 8, src_c0=16, width=24)
+    assert torch.equal(dst3[..., 8:32].float().cpu(), up[..., 16:40]) and float(dst3[..., :8].abs().sum()) == 0 and float(dst3[..., 32:].abs().sum()) == 0
+    with pytest.raises(nn_ops._lib.MindDetHipError):
+        nn_ops.upsample2x(x.to(DEV), dst3, 8, src_c0=48, width=24)   # slice beyond the source's channels
     dst2 = torch.zeros((1, 20, 24, 128), dtype=torch.bfloat16, device=DEV)
     nn_ops.concat_copy(x.to(DEV), dst2, 64)
     assert torch.equal(dst2[..., 64:].cpu(), x) and float(dst2[..., :64].abs().sum()) == 0
