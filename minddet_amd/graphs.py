@@ -1175,7 +1175,9 @@ class YOLOv8:
         heads = []
         for f, bx, cl in zip((o3, o4, o5), self.box, self.cls):
             n, h, w, _ = f.shape
-            head = torch.zeros((n, h, w, self.head_c), dtype=torch.bfloat16, device=f.device)
+            # (the two branch convs write every channel unless the class count needed padding to a multiple of 8: only then a zero fill)
+            full = self.head_c == 4 * self.reg_max + cl[2].cout
+            head = (torch.empty if full else torch.zeros)((n, h, w, self.head_c), dtype=torch.bfloat16, device=f.device)
             key = id(bx[0])
             if key not in self._stem2:                                      # the two branch stems read f once: one launch
                 self._stem2[key] = merged_conv([bx[0], cl[0]], f.device)
