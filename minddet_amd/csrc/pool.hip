@@ -147,7 +147,7 @@ __global__ void slice_write_kernel(const uint16_t *__restrict__ src, uint16_t *_
 // big window is reachable through an in-image centre -- and a square window's max is separable: rows first, then columns.  A workgroup
 // holds one image x CC 16-B channel groups in LDS: x, then the three row maxima, then the column maxima of those go out.  bf16 values are
 // mapped to order-preserving 16-bit keys (negative: all bits flipped, else the sign bit set) so that a max is one v_pk_max_u16 per pair.
-// Replaces three md_maxpool2d launches (25 global loads per output each) and four concat copies: 103 -> 9 us on YOLOv5s' 32 x 20 x 20 x 256.
+// Replaces three md_maxpool2d launches (25 global loads per output each) and four concat copies: 103 -> 22 us on YOLOv5s' 32 x 20 x 20 x 256.
 typedef unsigned short sp_u16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned sp_key(unsigned v) { return v ^ ((((v >> 15) & 0x00010001u) * 0x7fffu) | 0x80008000u); }
 __device__ __forceinline__ unsigned sp_unkey(unsigned k) { return k ^ ((((~k >> 15) & 0x00010001u) * 0x7fffu) | 0x80008000u); }
