@@ -304,6 +304,7 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
+constexpr int SCAN_KEEP_CAP = 4096;   // kept rows whose indices nms_scan_kernel holds in LDS (later ones are read back from its keep output)
 __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
@@ -324,7 +325,12 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long 
                                                         int *__restrict__ need_full = nullptr) {
     // n_limit / gate / need_full: the quota prefix pass of md_nms_aligned (see there).  A prefix pass looks at the first n_limit
     // boxes only and raises need_full[list] when they did not fill the quota although the list goes on.
-    extern __shared__ unsigned long long remv[];  // cb words + 1 (kept word broadcast)
+    // The removed-bits of a column block are taken when the scan REACHES the block: the OR over the rows kept so far of their words for
+    // that block -- one batch of independent loads per block (256 threads, the kept rows' indices in LDS), then the 64-step bit loop of
+    // wave 0.  (r04: the r01 form OR-ed every kept row into ALL later column blocks as soon as it was kept -- up to 16 dependent round
+    // trips per wave and block, most of them for blocks a quota'd scan never reaches: 8 us per block on the one-stage detectors' lists.)
+    extern __shared__ unsigned long long remv[];  // [0..3] per-wave partial ORs, [4] kept word broadcast (cb + 1 >= 5 words are allocated)
+    __shared__ int s_keep[SCAN_KEEP_CAP];
     const int list = blockIdx.x;
     if (gate && gate[list] == 0) return;
     const int n_all = count ? min(count[list], n_max) : n_max;
@@ -333,7 +339,6 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long 
     KeepT *keep = keep_all + (size_t)list * n_max;
     unsigned char *keepmask = keepmask_all ? keepmask_all + (size_t)list * n_max : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int j = tid; j < cb + 1; j += 256) remv[j] = 0ull;
     for (int i = tid; i < n_max; i += 256) {
         keep[i] = 0;
         if (keepmask) keepmask[i] = 0;
@@ -344,16 +349,23 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long 
     for (int blk = 0; blk < nb; ++blk) {
         if (max_output > 0 && total >= max_output) break;  // quota reached (uniform): nothing later can be kept
         const int base = blk * TILE;
+        const int r = base + lane;
+        unsigned long long diag = 0ull;
+        bool dead = r >= n;
+        if (wave == 0 && r < n) {   // requested together with the kept rows' words below
+            diag = mask[(size_t)r * cb + blk];
+            if (dead_area && dead_area[(size_t)r * dead_stride] == 0.f) dead = true;
+        }
+        unsigned long long v = 0ull;
+        for (int k = tid; k < total; k += 256) {
+            const int row = k < SCAN_KEEP_CAP ? s_keep[k] : (int)keep[k];
+            v |= mask[(size_t)row * cb + blk];
+        }
+        v = wave_or64(v);
+        if (lane == 0) remv[wave] = v;
+        __syncthreads();
         if (wave == 0) {
-            const int r = base + lane;
-            unsigned long long diag = 0ull;
-            bool dead = r >= n;
-            if (r < n) {
-                diag = mask[(size_t)r * cb + blk];
-                if (dead_area && dead_area[(size_t)r * dead_stride] == 0.f) dead = true;
-            }
-            unsigned long long cur = uniform64(remv[blk]) | __ballot(dead);
-            if (max_output > 0 && total >= max_output) cur = ~0ull;
+            unsigned long long cur = uniform64(remv[0] | remv[1] | remv[2] | remv[3]) | __ballot(dead);
             unsigned long long kept = 0ull;
             unsigned long long cand = ~cur;
             int quota = max_output > 0 ? max_output - total : 64;
@@ -369,22 +381,13 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long 
             if ((kept >> lane) & 1ull) {
                 const int pos = total + __popcll(kept & ((1ull << lane) - 1ull));
                 keep[pos] = (KeepT)r;
+                if (pos < SCAN_KEEP_CAP) s_keep[pos] = r;
                 if (keepmask) keepmask[r] = 1;
             }
-            if (lane == 0) remv[cb] = kept;
+            if (lane == 0) remv[4] = kept;
         }
-        __syncthreads();
-        const unsigned long long kept = uniform64(remv[cb]);
-        total += __popcll(kept);
-        // OR the kept rows' words into the removed-words of later column blocks:
-        // lane = row of this block, one wave per column block, DPP/shuffle OR-reduction.
-        const bool mine = (kept >> lane) & 1ull;
-        for (int j = blk + 1 + wave; j < nb; j += 4) {   // (column blocks past the last valid box carry no bits)
-            unsigned long long v = mine ? mask[(size_t)(base + lane) * cb + j] : 0ull;
-            v = wave_or64(v);
-            if (lane == 0) remv[j] |= v;
-        }
-        __syncthreads();
+        __syncthreads();   // (also makes this block's keep[] entries visible to the whole workgroup: one CU, one L1)
+        total += __popcll(uniform64(remv[4]));
     }
     if (tid == 0) {
         num_all[list] = total;
@@ -535,7 +538,7 @@ __global__ void iou_aligned_kernel(const float *__restrict__ boxes, int n, const
     out[idx] = v;
 }
 
-static inline size_t scan_lds(int cb) { return (size_t)(cb + 1) * sizeof(unsigned long long); }
+static inline size_t scan_lds(int cb) { return (size_t)(cb + 1 < 5 ? 5 : cb + 1) * sizeof(unsigned long long); }
 
 }  // namespace md
 
