@@ -300,6 +300,75 @@ __device__ __forceinline__ void topk_bitonic_regs(unsigned long long *sel, int P
     }
 }
 
+// P = 4096 keys, sorted ascending by 256 threads x 16 keys in registers.  The 12 index bits are split 4 | 4 | 4: in layout A a thread holds
+// bits 0-3 (16 consecutive keys), in B bits 4-7, in C bits 8-11, so EVERY compare-exchange stage is register-to-register (about 5
+// instructions per pair against about 30 per pair for a shuffled stage); between layouts the keys are transposed through LDS (one pad word
+// per 16 keys: 2-way conflicts at worst), 20 transposes in all.  r04, YOLO-sized segments: the sort fell from 34 to 12 us.
+// sel holds the keys in plain order on entry and on exit; it must have TOPK_SEL_SIZE entries.  All threads of the workgroup call it.
+constexpr int TOPK_SEL_SIZE = TOPK_MAXK + TOPK_MAXK / 16;
+template <int SHIFT>
+__device__ __forceinline__ void topk_blocked_stages(unsigned long long (&v)[16], int gbase, int size) {
+#pragma unroll
+    for (int rb = 3; rb >= 0; --rb) {
+        const int stride = 1 << (SHIFT + rb);
+        if (stride < size) {
+            constexpr int dummy = 0; (void)dummy;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if ((j & (1 << rb)) == 0) {
+                    const int g = gbase + (j << SHIFT);
+                    const bool up = (g & size) == 0;
+                    const unsigned long long a = v[j], b = v[j | (1 << rb)];
+                    const bool swap = (a > b) == up;
+                    v[j] = swap ? b : a;
+                    v[j | (1 << rb)] = swap ? a : b;
+                }
+            }
+        }
+    }
+}
+__device__ __forceinline__ void topk_bitonic_blocked_4096(unsigned long long *sel) {
+    const int tid = threadIdx.x;
+    const bool on = tid < 256;
+    const int t = tid & 255, lo = t & 15, hi = t >> 4;
+    unsigned long long v[16];
+    auto pad = [](int g) { return g + (g >> 4); };
+    // index of register j in the three layouts
+    auto gA = [&](int j) { return t * 16 + j; };
+    auto gB = [&](int j) { return hi * 256 + j * 16 + lo; };
+    auto gC = [&](int j) { return j * 256 + t; };
+    if (on) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = sel[gA(j)];
+    }
+    int layout = 0;   // 0 = A, 1 = B, 2 = C (uniform)
+    auto to_layout = [&](int want) __attribute__((always_inline)) {
+        if (want == layout) return;
+        __syncthreads();   // (the plain-order reads above / the previous transpose's reads are done)
+        if (on) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sel[pad(layout == 0 ? gA(j) : (layout == 1 ? gB(j) : gC(j)))] = v[j];
+        }
+        __syncthreads();
+        if (on) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = sel[pad(want == 0 ? gA(j) : (want == 1 ? gB(j) : gC(j)))];
+        }
+        layout = want;
+    };
+    for (int size = 2; size <= 4096; size <<= 1) {
+        if (size > 256) { to_layout(2); if (on) topk_blocked_stages<8>(v, t, size); }
+        if (size > 16) { to_layout(1); if (on) topk_blocked_stages<4>(v, hi * 256 + lo, size); }
+        to_layout(0);
+        if (on) topk_blocked_stages<0>(v, t * 16, size);
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sel[gA(j)] = v[j];
+    }
+}
+
 // One workgroup per segment.  Selects the k largest scores strictly greater than min_score
 // (ties resolved towards the LOWER index), returns them sorted descending (stable).
 // seg_off[L+1] (int32, elements).  out_val/out_idx are [L,k]; padded with (-FLT_MAX, 0); out_cnt[L].
@@ -308,7 +377,7 @@ __device__ __forceinline__ void topk_bitonic_regs(unsigned long long *sel, int P
 template <bool LK = false>
 __device__ void topk_block_select(const float *__restrict__ scores, const int *__restrict__ seg_off, int seg, int k,
                                   float min_score, float *__restrict__ out_val, int *__restrict__ out_idx,
-                                  int *__restrict__ out_cnt, unsigned long long *sel /* LDS, TOPK_MAXK entries */,
+                                  int *__restrict__ out_cnt, unsigned long long *sel /* LDS, TOPK_SEL_SIZE entries */,
                                   unsigned *lkeys = nullptr) {
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_remaining, s_count, s_wave_base[TOPK_THREADS / 64], s_tie_taken, s_tie_total;
@@ -485,7 +554,7 @@ __device__ void topk_block_select(const float *__restrict__ scores, const int *_
     // register-to-register, less than 64 E apart a wave shuffle, and only the farther ones (10 of the 78 stages at P = 4096) go through
     // LDS with workgroup barriers (r04: one barrier + LDS round trip per stage was 33 of the kernel's 73 us on YOLOv5s' segments)
     __syncthreads();
-    if (P > 2048) topk_bitonic_regs<4>(sel, P);
+    if (P > 2048) topk_bitonic_blocked_4096(sel);
     else if (P > 1024) topk_bitonic_regs<2>(sel, P);
     else topk_bitonic_regs<1>(sel, P);
     __syncthreads();
@@ -510,7 +579,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_segmented_kernel(const floa
                                                                       float min_score, float *__restrict__ out_val,
                                                                       int *__restrict__ out_idx,
                                                                       int *__restrict__ out_cnt) {
-    __shared__ unsigned long long sel[TOPK_MAXK];
+    __shared__ unsigned long long sel[TOPK_SEL_SIZE];
     topk_block_select(scores, seg_off, blockIdx.x, k, min_score, out_val, out_idx, out_cnt, sel);
 }
 
@@ -519,7 +588,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_segmented_kernel(const floa
 __global__ __launch_bounds__(TOPK_THREADS) void topk_segmented_lds_kernel(const float *__restrict__ scores, const int *__restrict__ seg_off, int k,
                                                                           float min_score, float *__restrict__ out_val, int *__restrict__ out_idx,
                                                                           int *__restrict__ out_cnt, int cap) {
-    __shared__ unsigned long long sel[TOPK_MAXK];
+    __shared__ unsigned long long sel[TOPK_SEL_SIZE];
     extern __shared__ __attribute__((aligned(16))) unsigned topk_lkeys[];
     const int n = seg_off[blockIdx.x + 1] - seg_off[blockIdx.x];
     if (n <= cap) topk_block_select<true>(scores, seg_off, blockIdx.x, k, min_score, out_val, out_idx, out_cnt, sel, topk_lkeys);
@@ -654,18 +723,12 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_final_kernel(const float *_
     int P = 1;
     while (P < (int)nc) P <<= 1;
     for (int i = tid; i < P; i += TOPK_THREADS) keys[i] = i < (int)nc ? cand[(size_t)seg * TK_CAP + i] : ~0ull;
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int t = tid; t < P / 2; t += TOPK_THREADS) {
-                const int lo = 2 * t - (t & (stride - 1));
-                const int hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const unsigned long long a = keys[lo], b = keys[hi];
-                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
-            }
-        }
-    }
+    __syncthreads();
+    // (r04: the register / shuffle forms of the single-workgroup select instead of one barrier + LDS round trip per stage)
+    if (P > 4096) topk_bitonic_regs<8>(keys, P);
+    else if (P > 2048) topk_bitonic_blocked_4096(keys);
+    else if (P > 1024) topk_bitonic_regs<2>(keys, P);
+    else topk_bitonic_regs<1>(keys, P);
     __syncthreads();
     const int kk = min(k, (int)nc);
     for (int i = tid; i < k; i += TOPK_THREADS) {
