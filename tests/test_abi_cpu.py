@@ -37,6 +37,17 @@ def test_wrong_nparam_is_an_error_code_not_a_crash():
         assert rc == 1  # iou-bev-nms-org.cpp:238 convention
 
 
+def test_round4_ops_argument_checks_without_a_gpu():
+    """md_c3_pair / md_sppf_pool refuse a wrong parameter count before touching anything, and md_sppf_pool_groups (a pure function: how
+    many 8-channel groups one workgroup holds in LDS, 0 = the map does not fit and the caller keeps three md_maxpool2d launches) answers on the CPU"""
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in ["md_c3_pair", "md_sppf_pool", "md_topk_segmented", "md_upsample2x"]:
+        assert getattr(lib, n)(1 if n != "md_sppf_pool" else 3, None, None, None, None, None, None) in (1, 2)
+    g = lib.md_sppf_pool_groups
+    assert g(20, 20, 256) == 4 and g(20, 20, 8) == 1 and g(40, 40, 128) == 1   # 400 px x 4 groups x 64 B = 100 KiB; 1600 px x 1 x 64 B = 100 KiB
+    assert g(80, 80, 64) == 0 and g(0, 20, 64) == 0 and g(20, 20, 12) == 0      # too large for LDS / empty / channels not a multiple of 8
+
+
 def test_no_process_wide_tuning_setters_and_reserved0_is_checked():
     """include/minddet_hip.h promises 're-entrant, no global mutable state': the conv family's tuning knobs are per-call attributes
     (md_conv_tune), the library exports no setter, and md_conv2d_attrs.reserved0 != 0 is MD_ERR_ARG (checked before any device call,
